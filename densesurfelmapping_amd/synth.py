@@ -1,0 +1,190 @@
+"""Deterministic synthetic driving scene: grey image + metric depth + camera pose.
+
+Replaces the reference's KITTI feed (``kitti_publisher/scripts/publisher.py:15-71``
+publishes mono8 ``/left_image`` and 32FC1 ``/depth_image``; poses come from
+ORB-SLAM2).  There is no dataset in this environment, so every test and the
+benchmark draw frames from this generator.
+
+Scene (camera convention of KITTI: x right, y down, z forward):
+  * ground plane ``y = +1.65`` m, side walls ``x = ±6`` m (4.65 m tall),
+  * axis-aligned boxes standing on the ground, laid out periodically along z,
+  * the camera drives along +z at ``step`` m/frame with a small periodic yaw and
+    lateral sway whose period equals the scene period, so frame ``t`` and frame
+    ``t + frames_per_period`` see the same image from a pose shifted by exactly
+    one period: an arbitrarily long replay needs only one period of images.
+
+All randomness is a counter-based 32-bit integer hash of (pixel, frame, seed),
+so the same bytes come out on any machine regardless of numpy's RNG streams.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+
+@dataclasses.dataclass(frozen=True)
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    far: float = 30.0
+    near: float = 0.5
+    rgbd: bool = False  # selects the RGB-D constant set of fusion_functions.h:17-21
+
+
+# Intrinsics named in SURVEY.md §8(d).
+KITTI_1226 = Camera(1226, 370, 707.0912, 707.0912, 601.8873, 183.1104)   # KITTI04-12.yaml:8-11
+KITTI_1241 = Camera(1241, 376, 718.856, 718.856, 607.1928, 185.2157)     # kitti_orb.launch:5-16
+VGA_RGBD = Camera(640, 480, 525.0, 525.0, 319.5, 239.5, far=6.0, near=0.3, rgbd=True)
+VGA_DRIVE = Camera(640, 480, 525.0, 525.0, 319.5, 239.5)
+FULLHD = Camera(1920, 1080, 1400.0, 1400.0, 959.5, 539.5)
+TINY = Camera(160, 96, 120.0, 120.0, 79.5, 47.5)                          # unit-test size
+
+
+def _hash32(x: np.ndarray) -> np.ndarray:
+    """lowbias32 integer hash, vectorised on uint32 (wrapping arithmetic)."""
+    x = x.astype(np.uint32, copy=True)
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7FEB352D)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846CA68B)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def _uniform01(idx: np.ndarray, salt: int) -> np.ndarray:
+    h = _hash32(idx.astype(np.uint32) ^ np.uint32(salt & 0xFFFFFFFF))
+    return (h >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+@dataclasses.dataclass
+class Scene:
+    seed: int = 12345
+    frames_per_period: int = 50
+    step: float = 0.8                # metres per frame (KITTI-like at 10 Hz)
+    yaw_amp_deg: float = 1.5
+    sway_amp: float = 0.25
+    depth_noise: float = 0.002       # multiplicative sigma
+    hole_fraction: float = 0.02
+    intensity_noise: float = 20.0
+    checker: float = 40.0            # +- amplitude of the 1 m world-space checker
+    max_depth: float = 80.0
+    n_boxes: int = 10
+    scale: float = 1.0               # shrink the whole scene (RGB-D range tests)
+
+    @property
+    def period(self) -> float:
+        return self.frames_per_period * self.step
+
+    def boxes(self) -> np.ndarray:
+        """[n,7]: xmin,xmax,ytop,zmin,zmax,albedo,_ within one period."""
+        out = np.zeros((self.n_boxes, 6), dtype=np.float64)
+        idx = np.arange(self.n_boxes, dtype=np.uint32)
+        r = lambda k: _uniform01(idx * np.uint32(7) + np.uint32(k), self.seed * 31 + 17)
+        cx = -4.5 + 9.0 * r(0)
+        # keep the driving corridor |x| < 1 free so the camera never enters a box
+        cx = np.where(np.abs(cx) < 1.8, np.sign(cx + 1e-9) * (1.8 + np.abs(cx)), cx)
+        wx = 0.6 + 1.2 * r(1)
+        hz = 0.8 + 2.0 * r(2)
+        hy = 0.6 + 1.8 * r(3)
+        cz = self.period * (idx + r(4)) / self.n_boxes
+        out[:, 0] = cx - wx / 2
+        out[:, 1] = cx + wx / 2
+        out[:, 2] = 1.65 - hy
+        out[:, 3] = cz
+        out[:, 4] = cz + hz
+        out[:, 5] = 60.0 + 140.0 * r(5)
+        out[:, :5] *= self.scale
+        return out
+
+    def pose(self, t: int) -> np.ndarray:
+        """cam->world 4x4 float32 for frame ``t`` (any non-negative integer)."""
+        ph = 2.0 * np.pi * (t % self.frames_per_period) / self.frames_per_period
+        yaw = np.deg2rad(self.yaw_amp_deg) * np.sin(ph)
+        c, s = np.cos(yaw), np.sin(yaw)
+        m = np.eye(4, dtype=np.float64)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+        m[0, 3] = self.sway_amp * np.sin(ph) * self.scale
+        m[2, 3] = self.step * t * self.scale
+        return m.astype(np.float32)
+
+
+def render(cam: Camera, scene: Scene, t: int):
+    """Return (image uint8 [H,W], depth float32 [H,W] metres, 0 = invalid, pose float32 4x4)."""
+    W, H = cam.width, cam.height
+    pose = scene.pose(t)
+    tl = t % scene.frames_per_period
+    P = pose.astype(np.float64)
+    # rendering happens in the first period's coordinates (scene is periodic in z)
+    org = np.array([P[0, 3], P[1, 3], scene.step * tl * scene.scale])
+    R = P[:3, :3]
+    u = (np.arange(W, dtype=np.float64) - cam.cx) / cam.fx
+    v = (np.arange(H, dtype=np.float64) - cam.cy) / cam.fy
+    dx_c = np.broadcast_to(u[None, :], (H, W))
+    dy_c = np.broadcast_to(v[:, None], (H, W))
+    dx = R[0, 0] * dx_c + R[0, 1] * dy_c + R[0, 2]
+    dy = R[1, 0] * dx_c + R[1, 1] * dy_c + R[1, 2]
+    dz = R[2, 0] * dx_c + R[2, 1] * dy_c + R[2, 2]
+    sc = scene.scale
+    best = np.full((H, W), np.inf)
+    albedo = np.zeros((H, W))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        # ground
+        tg = (1.65 * sc - org[1]) / dy
+        ok = (dy > 1e-9) & (tg > 0)
+        best = np.where(ok, tg, best)
+        albedo = np.where(ok, 110.0, albedo)
+        # walls
+        for sign, alb in ((-1.0, 150.0), (1.0, 90.0)):
+            tw = (sign * 6.0 * sc - org[0]) / dx
+            yh = org[1] + tw * dy
+            ok = (tw > 0) & (yh > -3.0 * sc) & (yh < 1.65 * sc) & (tw < best)
+            best = np.where(ok, tw, best)
+            albedo = np.where(ok, alb, albedo)
+        # boxes: this period and the next two (covers max_depth)
+        bx = scene.boxes()
+        for k in range(3):
+            for b in bx:
+                lo = np.array([b[0], b[2], b[3] + k * scene.period * sc])
+                hi = np.array([b[1], 1.65 * sc, b[4] + k * scene.period * sc])
+                t0x, t1x = (lo[0] - org[0]) / dx, (hi[0] - org[0]) / dx
+                t0y, t1y = (lo[1] - org[1]) / dy, (hi[1] - org[1]) / dy
+                t0z, t1z = (lo[2] - org[2]) / dz, (hi[2] - org[2]) / dz
+                tn = np.maximum(np.maximum(np.minimum(t0x, t1x), np.minimum(t0y, t1y)), np.minimum(t0z, t1z))
+                tf = np.minimum(np.minimum(np.maximum(t0x, t1x), np.maximum(t0y, t1y)), np.maximum(t0z, t1z))
+                ok = (tn <= tf) & (tn > 0) & (tn < best)
+                best = np.where(ok, tn, best)
+                albedo = np.where(ok, b[5], albedo)
+    hit = np.isfinite(best) & (best * 1.0 < scene.max_depth * sc)
+    tt = np.where(hit, best, 0.0)
+    # world-space checker (fixed to the world so consecutive frames agree)
+    wx = org[0] + tt * dx
+    wy = org[1] + tt * dy
+    wz = org[2] + tt * dz
+    cell = (np.floor(wx / sc + 1000.0) + np.floor(wy / sc + 1000.0) + np.floor(wz / sc + 1000.0)).astype(np.int64)
+    chk = np.where(cell & 1, scene.checker, -scene.checker)
+    pix = (np.arange(H * W, dtype=np.uint32)).reshape(H, W)
+    salt = scene.seed * 2654435761 + tl * 40503
+    n_int = _uniform01(pix, salt + 1) * scene.intensity_noise
+    img = np.where(hit, albedo + chk + n_int, 200.0 + n_int)  # sky is bright
+    image = np.clip(np.floor(img), 0, 255).astype(np.uint8)
+    n_d = _uniform01(pix, salt + 2) - 0.5
+    depth = tt * (1.0 + scene.depth_noise * n_d)  # camera-frame z == ray parameter (dir_c.z = 1)
+    holes = _uniform01(pix, salt + 3) < scene.hole_fraction
+    depth = np.where(hit & ~holes, depth, 0.0).astype(np.float32)
+    return image, depth, pose
+
+
+def sequence(cam: Camera, scene: Scene, n_frames: int, start: int = 0):
+    """Yield (t, image, depth, pose, ref_idx): every 5th frame is a keyframe and
+    ``ref_idx`` is the index of the latest keyframe."""
+    cache = {}
+    for t in range(start, start + n_frames):
+        tl = t % scene.frames_per_period
+        if tl not in cache:
+            cache[tl] = render(cam, scene, tl)[:2]
+        image, depth = cache[tl]
+        yield t, image, depth, scene.pose(t), (t - start) // 5
