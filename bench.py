@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Benchmark of the per-frame surfel-fusion hot path (BASELINE.json: depth frames fused/sec @ 1226x370).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE configs[1] -- synthetic KITTI-shaped replay, 1226x370, one frame
+= SLIC superpixels + normals/plane fit + projective fuse + new surfels + map compaction
+(FusionFunctions::fuse_initialize_map + SurfelMap::fuse_map), inputs resident in HBM.  Each rank owns
+one GPU and replays B independent subsequences on B handles (streams); one STEP advances every
+subsequence of the rank by one frame, so a step fuses B frames per GPU.  There is no collective on the
+data path (weak scaling: work per GPU is fixed); the final clouds are merged once, outside the timed
+region, with an RCCL all-gather.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def stage_alg_bytes(stage, cam, n_seed, m_avg, k_avg):
+    """Algorithmic bytes one launch of `stage` must move: planes it has to read or
+    write once, nothing for re-reads of overlapping windows or intermediates."""
+    n = cam.width * cam.height
+    base = stage.rstrip("_012")
+    if base == "assign":
+        first = stage.endswith("_0")
+        return n * (1 + 4) + n * 4 + (0 if first else n * 4) + n_seed * 24
+    if base == "apply":
+        return n * 4 * 3
+    if base == "update_seeds":
+        return n * (4 + 1 + 4) + n_seed * 32
+    if base == "seed_planes":
+        return n * (4 + 4) + n_seed * (16 + 60)
+    if base == "fuse_surfels":
+        return m_avg * 88
+    if base == "new_surfels":
+        return n_seed * 60 + k_avg * 44
+    if base == "compact":
+        return k_avg * 88
+    if base == "hole_scan":
+        return m_avg / 8
+    return n_seed * 16
+
+
+def cpu_baseline(cam, scene, synth, budget_s=12.0):
+    """The reference's own fusion_functions.cpp (oracle/_ref, real 10-thread schedule) if its prebuilt
+    library is present, else our C restatement (1 thread), on a bounded sample of the same workload."""
+    from oracle import bindings as ob
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    if ob.have_ref("threads"):
+        orc, kind, cores = ob.RefOracle(cam, kind="threads"), "reference", min(10, os.cpu_count() or 1)
+    else:
+        orc, kind, cores = ob.PortOracle(cam), "port", 1
+    local = np.zeros(0, ob.SURFEL_DTYPE)
+    frames = list(synth.sequence(cam, scene, 40))
+    orc.fuse_map(frames[0][4], frames[0][1], frames[0][2], frames[0][3], local)  # warm-up, discarded
+    t0 = time.perf_counter()
+    n = 0
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    os.dup2(devnull, 1)  # the reference prints timers on every frame
+    try:
+        for t, img, dep, pose, ref in frames:
+            local, _ = orc.fuse_map(ref, img, dep, pose, local)
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    finally:
+        os.dup2(saved, 1)
+        os.close(devnull)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": kind,
+            "host_cpus": os.cpu_count(),
+            "sample": f"first {n} frames of the same synthetic 1226x370 sequence, fuse_map incl. compaction, "
+                      f"{'10 std::threads as in the reference' if kind == 'reference' else 'scalar C restatement'}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSM_BENCH_STREAMS", "8")),
+                    help="independent subsequences (handles/streams) per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from densesurfelmapping_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    cam = synth.KITTI_1226
+    B, K, W = args.streams, args.steps, args.warmup
+    period = 50
+    n_seed = (cam.width // 8) * (cam.height // 8)
+
+    # one scene period of frames per rank (seed differs per rank); the rank's B subsequences replay
+    # the same images into B independent maps
+    scene = synth.Scene(seed=12345 + 1000 * rank, frames_per_period=period)
+    rendered = [synth.render(cam, scene, i)[:2] for i in range(period)]
+    handles, plans = [], []
+    for b in range(B):
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=1 << 21)
+        for i, (img, dep) in enumerate(rendered):
+            ff.frame_upload(i, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        total = W + K
+        slots = [t % period for t in range(total)]
+        refs = [t // 5 for t in range(total)]
+        poses = np.stack([scene.pose(t) for t in range(total)])
+        plans.append(api.FusionFunctions.pack_replay(slots, refs, poses))
+        handles.append(ff)
+
+    def run(lo, hi, chunk=25):
+        for c0 in range(lo, hi, chunk):
+            c1 = min(hi, c0 + chunk)
+            for ff, (s, r, p) in zip(handles, plans):
+                ff.replay_enqueue(s[c0:c1], r[c0:c1], p[c0:c1])
+
+    def sync_all():
+        for ff in handles:
+            ff.synchronize()
+        torch.cuda.synchronize()
+
+    run(0, W)
+    sync_all()
+    m_start = [ff.map_size() for ff in handles]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, W + K)
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    m_end = [ff.map_size() for ff in handles]
+
+    # merge of the final clouds (outside the timed region): RCCL all-gather over xGMI
+    merged_total = sum(m_end)
+    if world > 1:
+        from densesurfelmapping_amd.replay import merge_clouds
+        clouds = []
+        for ff, m in zip(handles, m_end):
+            buf = torch.empty(m * 44, dtype=torch.uint8, device=f"cuda:{device}")
+            ff.map_copy_to_device(buf.data_ptr(), m)
+            clouds.append(buf)
+        merged, counts = merge_clouds(torch.cat(clouds))
+        merged_total = int(sum(counts))
+
+    frames_total = world * B * K
+    fps = frames_total / dt
+    m_avg = float(np.mean([(a + b) / 2 for a, b in zip(m_start, m_end)]))
+    k_avg = 1400.0
+    n = cam.width * cam.height
+    b_alg_frame = 9 * n + 60 * n_seed + 88 * m_avg + 44 * k_avg
+
+    out = {
+        "metric": "depth frames fused/sec @ KITTI 1226x370",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic KITTI-shaped replay 1226x370, full superpixel+normal+"
+                               "fuse+compaction HIP path, frames and map resident in HBM",
+                   "subsequences_per_gpu": B, "frames_per_step_per_gpu": B, "scene_period_frames": period,
+                   "mean_live_surfels": round(m_avg), "final_surfels_all_ranks": merged_total,
+                   "parallelism": f"{world} GPU x {B} independent subsequences, all-gather of final cloud only"},
+        "e2e_algorithmic_GBps": round(fps * b_alg_frame / 1e9, 2),
+        "e2e_hbm_frac": round(fps * b_alg_frame / 1e9 / (HBM_PEAK_GBS * world), 5),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-kernel durations, measured live with HIP events on the handle's own stream (eager replay
+        # of the same workload on a fresh handle; a long delay kernel in front of each frame keeps the
+        # host launch latency out of the intervals)
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=1 << 21)
+        for i, (img, dep) in enumerate(rendered):
+            ff.frame_upload(i, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        nt = min(W + K, 120)
+        s, r, p = plans[0][0][:nt], plans[0][1][:nt], plans[0][2][:nt]
+        ff.replay_enqueue(s[:20], r[:20], p[:20])
+        ff.synchronize()
+        m0 = ff.map_size()
+        stages, nfr = ff.replay_timed(s[20:], r[20:], p[20:])
+        m1 = ff.map_size()
+        mt = (m0 + m1) / 2
+        per = {k: v[0] / max(v[1], 1) * 1e3 for k, v in stages.items()}  # us per launch
+        dom = max(per, key=per.get)
+        alg = stage_alg_bytes(dom, cam, n_seed, mt, k_avg)
+        achieved = alg / (per[dom] * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "alg_bytes_per_launch": int(alg), "avg_launch_us": round(per[dom], 2)}
+        out["kernel_us"] = {k: round(v, 2) for k, v in per.items()}
+        out["frame_kernel_sum_us"] = round(sum(per.values()), 1)
+        ksum = sum(per.values()) * 1e-6
+        b_alg_t = 9 * n + 60 * n_seed + 88 * mt + 44 * k_avg
+        out["kernel_time_weighted_hbm_frac"] = round(b_alg_t / ksum / 1e9 / HBM_PEAK_GBS, 5)
+        ff.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cam, synth.Scene(seed=12345, frames_per_period=period), synth)
+
+    if rank == 0:
+        print(json.dumps(out))
+    for ff in handles:
+        ff.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

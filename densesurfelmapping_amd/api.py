@@ -1,0 +1,286 @@
+"""Host-side mirror of the reference's per-frame fusion interface, over the C ABI of include/dsm.h.
+
+Reference (C++) interface mirrored here, same names and argument meaning:
+
+  * ``FusionFunctions::initialize(w, h, fx, fy, cx, cy, far, near)``
+    -- surfel_fusion/src/fusion_functions.h:84-87
+  * ``FusionFunctions::fuse_initialize_map(reference_frame_index, image, depth, pose,
+    local_surfels, new_surfels)`` -- fusion_functions.h:88-94, fusion_functions.cpp:30-83
+  * ``SurfelMap::fuse_map(image, depth, pose, reference_index)`` -- surfel_map.cpp:1060-1113
+
+``SurfelElement`` / ``Superpixel_seed`` arrays are numpy structured arrays with the reference's
+byte layout (elements.h:5-31).  All compute happens in the HIP library; if it cannot be loaded, or
+no gfx950 device is present, construction raises -- there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdsm_hip.so")
+
+SURFEL_DTYPE = np.dtype(
+    [("px", "<f4"), ("py", "<f4"), ("pz", "<f4"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"),
+     ("size", "<f4"), ("color", "<f4"), ("weight", "<f4"), ("update_times", "<i4"), ("last_update", "<i4")]
+)  # elements.h:22-31
+SEED_DTYPE = np.dtype(
+    {"names": ["x", "y", "size", "norm_x", "norm_y", "norm_z", "posi_x", "posi_y", "posi_z", "view_cos",
+               "mean_depth", "mean_intensity", "fused", "stable", "min_eigen_value", "max_eigen_value"],
+     "formats": ["<f4"] * 12 + ["u1", "u1", "<f4", "<f4"],
+     "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 49, 52, 56],
+     "itemsize": 60}
+)  # elements.h:5-20
+assert SURFEL_DTYPE.itemsize == 44 and SEED_DTYPE.itemsize == 60
+
+DSM_FLAG_NO_GRAPH = 1
+DSM_MAX_STAGES = 32
+
+# every symbol include/dsm.h declares
+ABI_SYMBOLS = (
+    "dsm_abi_version", "dsm_config_init", "dsm_create", "dsm_destroy", "dsm_last_error",
+    "dsm_fuse_initialize_map", "dsm_fuse_map",
+    "dsm_map_upload", "dsm_map_size", "dsm_map_download", "dsm_map_copy_to_device",
+    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
+    "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
+    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed",
+)
+
+
+class DsmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dsm error {code}: {msg}")
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("far_dist", C.c_float), ("near_dist", C.c_float),
+                ("huber_range", C.c_double), ("baseline", C.c_double),
+                ("disparity_error", C.c_double), ("min_tolerate_diff", C.c_double),
+                ("device", C.c_int32), ("surfel_capacity", C.c_int32), ("frame_slots", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class _StageTimes(C.Structure):
+    _fields_ = [("n_stages", C.c_int32), ("name", C.c_char_p * DSM_MAX_STAGES),
+                ("ms", C.c_double * DSM_MAX_STAGES), ("launches", C.c_int64 * DSM_MAX_STAGES),
+                ("frames", C.c_int64)]
+
+
+_vp = C.c_void_p
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m densesurfelmapping_amd.build` "
+            "(hipcc, gfx950). This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.dsm_last_error.restype = C.c_char_p
+    lib.dsm_last_error.argtypes = [_vp]
+    lib.dsm_config_init.argtypes = [C.POINTER(_Config), C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_int]
+    lib.dsm_create.argtypes = [C.POINTER(_Config), C.POINTER(_vp)]
+    lib.dsm_destroy.argtypes = [_vp]
+    lib.dsm_destroy.restype = None
+    lib.dsm_fuse_initialize_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int32,
+                                            _vp, C.c_int32, _vp]
+    lib.dsm_fuse_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_int32, _vp]
+    lib.dsm_map_upload.argtypes = [_vp, _vp, C.c_int32]
+    lib.dsm_map_size.argtypes = [_vp, _vp]
+    lib.dsm_map_download.argtypes = [_vp, _vp, C.c_int32, _vp]
+    lib.dsm_map_copy_to_device.argtypes = [_vp, _vp, C.c_int32, _vp]
+    lib.dsm_frame_upload.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
+    lib.dsm_frame_upload_device.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
+    lib.dsm_fuse_frame_resident.argtypes = [_vp, C.c_int, C.c_int, _vp]
+    lib.dsm_replay_enqueue.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
+    lib.dsm_synchronize.argtypes = [_vp]
+    lib.dsm_last_new_count.argtypes = [_vp, _vp]
+    lib.dsm_stream.argtypes = [_vp, C.POINTER(_vp)]
+    lib.dsm_get_labels.argtypes = [_vp, _vp]
+    lib.dsm_get_seeds.argtypes = [_vp, _vp]
+    lib.dsm_seed_count.argtypes = [_vp]
+    lib.dsm_replay_timed.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.POINTER(_StageTimes)]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+def pose_to_colmajor(pose) -> np.ndarray:
+    """4x4 cam->world matrix (row-major numpy) -> the 16 floats of an Eigen::Matrix4f."""
+    p = np.asarray(pose, np.float32)
+    if p.shape != (4, 4):
+        raise ValueError("pose must be 4x4")
+    return np.ascontiguousarray(p.T).ravel()
+
+
+class FusionFunctions:
+    """Drop-in for the reference's ``FusionFunctions`` (one instance = one handle = one stream)."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = None
+
+    # fusion_functions.h:84-87; the keyword arguments are what an HBM-resident engine adds
+    def initialize(self, width, height, fx, fy, cx, cy, far_dist, near_dist, *, rgbd=False, device=0,
+                   surfel_capacity=0, frame_slots=0, flags=0):
+        self.close()
+        cfg = _Config()
+        rc = self._lib.dsm_config_init(C.byref(cfg), width, height, fx, fy, cx, cy, far_dist, near_dist,
+                                       1 if rgbd else 0)
+        if rc:
+            raise DsmError(rc, "dsm_config_init")
+        cfg.device, cfg.surfel_capacity, cfg.frame_slots, cfg.flags = device, surfel_capacity, frame_slots, flags
+        h = _vp()
+        rc = self._lib.dsm_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise DsmError(rc, self._lib.dsm_last_error(None).decode())
+        self._h = h
+        self.width, self.height = width, height
+        self.n_seed = self._lib.dsm_seed_count(h)
+        return self
+
+    @classmethod
+    def from_camera(cls, cam, **kw):
+        return cls().initialize(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near,
+                                rgbd=getattr(cam, "rgbd", False), **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dsm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise DsmError(rc, self._lib.dsm_last_error(self._h).decode())
+
+    def _frame_args(self, image, depth):
+        image = np.asarray(image)
+        depth = np.asarray(depth)
+        if image.dtype != np.uint8 or depth.dtype != np.float32:
+            raise TypeError("image must be uint8 (CV_8UC1) and depth float32 (CV_32FC1)")
+        if image.shape != (self.height, self.width) or depth.shape != (self.height, self.width):
+            raise ValueError("image/depth shape does not match initialize()")
+        if image.strides[1] != 1 or depth.strides[1] != 4:
+            image, depth = np.ascontiguousarray(image), np.ascontiguousarray(depth)
+        return image, depth
+
+    # fusion_functions.h:88-94: returns (local_surfels updated, new_surfels)
+    def fuse_initialize_map(self, reference_frame_index, image, depth, pose, local_surfels):
+        image, depth = self._frame_args(image, depth)
+        pose_cm = pose_to_colmajor(pose)
+        local = np.ascontiguousarray(local_surfels, SURFEL_DTYPE).copy()
+        fresh = np.zeros(self.n_seed, SURFEL_DTYPE)
+        n_new = C.c_int32(0)
+        self._check(self._lib.dsm_fuse_initialize_map(
+            self._h, reference_frame_index, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0],
+            _ptr(pose_cm), _ptr(local), len(local), _ptr(fresh), len(fresh), C.byref(n_new)))
+        return local, fresh[: n_new.value].copy()
+
+    # SurfelMap::fuse_map (surfel_map.cpp:1060-1113): returns (local_surfels after compaction, n_new)
+    def fuse_map(self, reference_frame_index, image, depth, pose, local_surfels):
+        image, depth = self._frame_args(image, depth)
+        pose_cm = pose_to_colmajor(pose)
+        cap = len(local_surfels) + self.n_seed
+        buf = np.zeros(cap, SURFEL_DTYPE)
+        buf[: len(local_surfels)] = local_surfels
+        n_local = C.c_int32(len(local_surfels))
+        n_new = C.c_int32(0)
+        self._check(self._lib.dsm_fuse_map(
+            self._h, reference_frame_index, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0],
+            _ptr(pose_cm), _ptr(buf), C.byref(n_local), cap, C.byref(n_new)))
+        return buf[: n_local.value].copy(), n_new.value
+
+    # ---- resident path -------------------------------------------------------------------
+    def map_upload(self, surfels):
+        a = np.ascontiguousarray(surfels, SURFEL_DTYPE)
+        self._check(self._lib.dsm_map_upload(self._h, _ptr(a), len(a)))
+
+    def map_size(self) -> int:
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_map_size(self._h, C.byref(n)))
+        return n.value
+
+    def map_download(self) -> np.ndarray:
+        n = self.map_size()
+        out = np.zeros(max(n, 1), SURFEL_DTYPE)
+        m = C.c_int32(0)
+        self._check(self._lib.dsm_map_download(self._h, _ptr(out), len(out), C.byref(m)))
+        return out[: m.value].copy()
+
+    def map_copy_to_device(self, dst_ptr: int, cap: int) -> int:
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_map_copy_to_device(self._h, _vp(dst_ptr), cap, C.byref(n)))
+        return n.value
+
+    def frame_upload(self, slot, image, depth):
+        image, depth = self._frame_args(image, depth)
+        self._check(self._lib.dsm_frame_upload(self._h, slot, _ptr(image), image.strides[0], _ptr(depth),
+                                               depth.strides[0]))
+
+    def frame_upload_device(self, slot, image_ptr, img_step, depth_ptr, depth_step):
+        self._check(self._lib.dsm_frame_upload_device(self._h, slot, _vp(image_ptr), img_step, _vp(depth_ptr),
+                                                      depth_step))
+
+    def fuse_frame_resident(self, slot, reference_frame_index, pose):
+        pose_cm = pose_to_colmajor(pose)
+        self._check(self._lib.dsm_fuse_frame_resident(self._h, slot, reference_frame_index, _ptr(pose_cm)))
+
+    @staticmethod
+    def pack_replay(slots, ref_idx, poses):
+        slots = np.ascontiguousarray(slots, np.int32)
+        ref_idx = np.ascontiguousarray(ref_idx, np.int32)
+        poses_cm = np.ascontiguousarray(np.asarray(poses, np.float32).transpose(0, 2, 1)).reshape(len(slots), 16)
+        return slots, ref_idx, poses_cm
+
+    def replay_enqueue(self, slots, ref_idx, poses_cm):
+        """slots/ref_idx int32 [n], poses_cm float32 [n,16] column-major (see pack_replay)."""
+        self._check(self._lib.dsm_replay_enqueue(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm)))
+
+    def synchronize(self):
+        self._check(self._lib.dsm_synchronize(self._h))
+
+    def last_new_count(self) -> int:
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_last_new_count(self._h, C.byref(n)))
+        return n.value
+
+    def stream(self) -> int:
+        s = _vp()
+        self._check(self._lib.dsm_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    # ---- parity taps -----------------------------------------------------------------------
+    def labels(self) -> np.ndarray:  # FusionFunctions::superpixel_index
+        out = np.zeros((self.height, self.width), np.int32)
+        self._check(self._lib.dsm_get_labels(self._h, _ptr(out)))
+        return out
+
+    def seeds(self) -> np.ndarray:  # FusionFunctions::superpixel_seeds
+        out = np.zeros(self.n_seed, SEED_DTYPE)
+        self._check(self._lib.dsm_get_seeds(self._h, _ptr(out)))
+        return out
+
+    def replay_timed(self, slots, ref_idx, poses_cm):
+        """Eager replay with a HIP event pair around every kernel; returns {stage: (ms_total, launches)}."""
+        st = _StageTimes()
+        self._check(self._lib.dsm_replay_timed(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm),
+                                               C.byref(st)))
+        return {st.name[i].decode(): (st.ms[i], st.launches[i]) for i in range(st.n_stages)}, st.frames

@@ -1,0 +1,54 @@
+"""Build the HIP shared library in-tree (gfx950 only).
+
+    python -m densesurfelmapping_amd.build
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is mandatory: results must match the
+reference's non-fused IEEE arithmetic bit for bit (surfel_fusion/CMakeLists.txt:7-8 builds the
+reference without -march / -ffast-math).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_NAME = "libdsm_hip.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+SOURCES = ["dsm_kernels.hip", "dsm_api.hip"]
+HEADERS = ["dsm_math.h", "dsm_device.h", os.path.join("..", "..", "include", "dsm.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,526 @@
+// dsm_api.hip -- the C ABI of include/dsm.h: handle, HBM buffers, stream, hipGraph replay.
+//
+// Host-side arithmetic is limited to the 4x4 pose inverse (FF.cpp:59, fp32), done with the same
+// inverse4<float> the oracle uses; everything else runs in dsm_kernels.hip.  There is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dsm_device.h"
+
+using namespace dsm;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int kParamRing = 4096;
+constexpr int kDefaultCapacity = 4 * 1024 * 1024;
+
+} // namespace
+
+struct dsm_handle {
+    dsm_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceCtx hc;              // host copy of the device context
+    DeviceCtx *d_ctx = nullptr;
+    std::vector<void *> allocs; // every hipMalloc of this handle
+    FrameParams *h_params = nullptr; // pinned staging ring
+    int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
+    FrameParams *d_params = nullptr;
+    hipGraphExec_t graph[2] = {nullptr, nullptr}; // [with_compaction]
+    int graph_fuse_bound = 0;
+    int64_t frames_submitted = 0, frames_done = 0;
+    int map_upper = 0; // host-side upper bound of the resident map size
+    bool map_valid = false;
+    hipEvent_t ev[kNumStages + 1];
+    bool have_events = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(dsm_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(h, DSM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T> hipError_t dev_alloc(dsm_handle *h, T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T) + 256);
+    if (e != hipSuccess) return e;
+    h->allocs.push_back(p);
+    *out = (T *)p;
+    return hipMemsetAsync(p, 0, count * sizeof(T) + 256, h->stream);
+}
+
+int bind_device(dsm_handle *h) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    return DSM_OK;
+}
+
+// make room in the parameter rings for n more frames
+int reserve_params(dsm_handle *h, int n) {
+    if (h->frames_submitted + n - h->frames_done > kParamRing) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->frames_done = h->frames_submitted;
+    }
+    return DSM_OK;
+}
+
+int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16) {
+    if (slot < 0 || slot >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slot, h->hc.n_slots);
+    int rc = reserve_params(h, 1);
+    if (rc) return rc;
+    const int ring = (int)(h->frames_submitted % kParamRing);
+    FrameParams &fp = h->h_params[ring];
+    memcpy(fp.pose, pose16, sizeof fp.pose);
+    inverse4<float>(fp.pose, fp.inv); // FF.cpp:59
+    fp.ref_idx = ref_idx;
+    fp.slot = slot;
+    fp.pad[0] = fp.pad[1] = 0;
+    HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, &fp, sizeof fp, hipMemcpyHostToDevice, h->stream));
+    return DSM_OK;
+}
+
+int fuse_grid_bound(const dsm_handle *h) { return h->hc.cap; }
+
+int ensure_graph(dsm_handle *h, bool with_compaction) {
+    hipGraphExec_t &ge = h->graph[with_compaction ? 1 : 0];
+    if (ge) return DSM_OK;
+    hipGraph_t g = nullptr;
+    HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t le = launch_frame(h->d_ctx, h->hc, fuse_grid_bound(h), with_compaction, h->stream, nullptr);
+    hipError_t ce = hipStreamEndCapture(h->stream, &g);
+    if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
+    if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+    return DSM_OK;
+}
+
+// enqueue the kernels of one frame whose params were staged by stage_params
+int submit_frame(dsm_handle *h, bool with_compaction) {
+    if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
+        hipError_t e = launch_frame(h->d_ctx, h->hc, h->map_upper, with_compaction, h->stream, nullptr);
+        if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    } else {
+        int rc = ensure_graph(h, with_compaction);
+        if (rc) return rc;
+        HIP_TRY(h, hipGraphLaunch(h->graph[with_compaction ? 1 : 0], h->stream));
+    }
+    h->frames_submitted++;
+    if (with_compaction) {
+        h->map_upper += h->hc.n_seed;
+        if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
+    }
+    return DSM_OK;
+}
+
+int check_status(dsm_handle *h) {
+    // caller has synchronised and copied status into h_scalars[2]
+    const int st = h->h_scalars[2];
+    if (st & kStatusCapacity) return fail(h, DSM_E_CAPACITY, "resident surfel capacity %d exceeded", h->hc.cap);
+    if (st & kStatusBadPick) return fail(h, DSM_E_INVALID, "a pixel had no candidate superpixel (unsupported image size)");
+    return DSM_OK;
+}
+
+int sync_and_fetch_counts(dsm_handle *h) {
+    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[0], h->hc.n_local, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[1], h->hc.n_new, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[2], h->hc.status, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->frames_done = h->frames_submitted;
+    h->map_upper = h->h_scalars[0];
+    return check_status(h);
+}
+
+int upload_frame(dsm_handle *h, int slot, const void *image, size_t img_step, const void *depth, size_t depth_step,
+                 hipMemcpyKind kind) {
+    if (!image || !depth) return fail(h, DSM_E_INVALID, "null image/depth");
+    if (slot < 0 || slot >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slot, h->hc.n_slots);
+    const int w = h->hc.w, hh = h->hc.h, pitch = h->hc.pitch;
+    if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
+    uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot * h->hc.slot_elems;
+    float *dd = (float *)h->hc.depth_base + (int64_t)slot * h->hc.slot_elems;
+    HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, kind, h->stream));
+    HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, kind, h->stream));
+    return DSM_OK;
+}
+
+int set_map(dsm_handle *h, const dsm_surfel *src, int n) {
+    if (n < 0 || (n > 0 && !src)) return fail(h, DSM_E_INVALID, "bad surfel array");
+    if (n > h->hc.cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the handle's capacity %d", n, h->hc.cap);
+    if (n) HIP_TRY(h, hipMemcpyAsync(h->hc.local, src, (size_t)n * sizeof(dsm_surfel), hipMemcpyHostToDevice, h->stream));
+    // the 4-byte count goes through a pinned scratch word; wait so that it can be reused at once
+    h->h_scalars[3] = n;
+    HIP_TRY(h, hipMemcpyAsync(h->hc.n_local, &h->h_scalars[3], 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->frames_done = h->frames_submitted;
+    h->map_upper = n;
+    h->map_valid = true;
+    return DSM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int dsm_abi_version(void) { return DSM_ABI_VERSION; }
+
+int dsm_config_init(dsm_config *cfg, int width, int height, float fx, float fy, float cx, float cy, float far_dist,
+                    float near_dist, int rgbd) {
+    if (!cfg) return DSM_E_INVALID;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->width = width; cfg->height = height;
+    cfg->fx = fx; cfg->fy = fy; cfg->cx = cx; cfg->cy = cy;
+    cfg->far_dist = far_dist; cfg->near_dist = near_dist;
+    if (rgbd) { // fusion_functions.h:17-21
+        cfg->huber_range = 0.05; cfg->baseline = 0.08; cfg->disparity_error = 1.0; cfg->min_tolerate_diff = 0.05;
+    } else { // fusion_functions.h:13-16
+        cfg->huber_range = 0.4; cfg->baseline = 0.5; cfg->disparity_error = 4.0; cfg->min_tolerate_diff = 0.1;
+    }
+    return DSM_OK;
+}
+
+const char *dsm_last_error(const dsm_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dsm_create(const dsm_config *cfg, dsm_handle **out) {
+    if (!cfg || !out) return fail(nullptr, DSM_E_INVALID, "null argument");
+    *out = nullptr;
+    const int w = cfg->width, hh = cfg->height;
+    if (w < 3 * kCell || hh < 3 * kCell || w > 32767 || hh > 32767)
+        return fail(nullptr, DSM_E_INVALID, "image size %dx%d out of range", w, hh);
+    // A ragged border wider than 4 pixels leaves pixels with no candidate seed; the reference then
+    // indexes superpixel_seeds[-1] (FF.cpp:442-451).  Refuse instead of inventing behaviour.
+    if (w % kCell > kCell / 2 || hh % kCell > kCell / 2)
+        return fail(nullptr, DSM_E_INVALID, "image size %dx%d: (size mod 8) > 4 is undefined in the reference", w, hh);
+    if (!(cfg->fx != 0) || !(cfg->fy != 0)) return fail(nullptr, DSM_E_INVALID, "zero focal length");
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(nullptr, DSM_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= n_dev) return fail(nullptr, DSM_E_NO_DEVICE, "device %d not present", cfg->device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, DSM_E_NO_DEVICE, "cannot query device");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, DSM_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
+
+    dsm_handle *h = new (std::nothrow) dsm_handle();
+    if (!h) return fail(nullptr, DSM_E_HIP, "out of host memory");
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    int rc = DSM_OK;
+    auto bail = [&](int code) {
+        g_create_error = h->err;
+        dsm_destroy(h);
+        return code;
+    };
+#define CREATE_TRY(expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            fail(h, DSM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));                   \
+            return bail(DSM_E_HIP);                                                       \
+        }                                                                                 \
+    } while (0)
+    CREATE_TRY(hipSetDevice(h->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+    DeviceCtx &c = h->hc;
+    memset(&c, 0, sizeof c);
+    c.w = w; c.h = hh;
+    c.pitch = (w + 63) / 64 * 64;
+    c.gw = w / kCell; c.gh = hh / kCell; // FF.cpp:14-15
+    c.n_seed = c.gw * c.gh;
+    c.k.fx = cfg->fx; c.k.fy = cfg->fy; c.k.cx = cfg->cx; c.k.cy = cfg->cy;
+    c.far_d = cfg->far_dist; c.near_d = cfg->near_dist;
+    c.huber = cfg->huber_range; c.baseline = cfg->baseline;
+    c.disp_err = cfg->disparity_error; c.min_tol = cfg->min_tolerate_diff;
+    c.slot_elems = (int64_t)c.pitch * c.h;
+    c.n_slots = cfg->frame_slots > 0 ? cfg->frame_slots : 2;
+    c.cap = cfg->surfel_capacity > 0 ? cfg->surfel_capacity : kDefaultCapacity;
+    c.cap = (c.cap + 63) / 64 * 64;
+    c.n_params = kParamRing;
+
+    uint8_t *img = nullptr; float *dep = nullptr;
+    CREATE_TRY(dev_alloc(h, &img, (size_t)c.slot_elems * c.n_slots));
+    CREATE_TRY(dev_alloc(h, &dep, (size_t)c.slot_elems * c.n_slots));
+    c.img_base = img; c.depth_base = dep;
+    CREATE_TRY(dev_alloc(h, &c.label, (size_t)c.slot_elems));
+    CREATE_TRY(dev_alloc(h, &c.cand, (size_t)c.slot_elems));
+    CREATE_TRY(dev_alloc(h, &c.worklist, (size_t)c.slot_elems));
+    CREATE_TRY(dev_alloc(h, &c.core, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.inv_depth, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.core_stage, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.stable_stage, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.tmin, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.first_empty, (size_t)kSweeps * kWorkers));
+    CREATE_TRY(dev_alloc(h, &c.seeds, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.local, (size_t)c.cap));
+    CREATE_TRY(dev_alloc(h, &c.fresh, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.hole_mask, (size_t)c.cap / 64 + 1));
+    CREATE_TRY(dev_alloc(h, &c.wave_prefix, (size_t)c.cap / 64 + 1));
+    CREATE_TRY(dev_alloc(h, &c.holes, (size_t)c.cap));
+    int32_t *scalars = nullptr; // work_count, n_local, n_local_next, n_new, n_holes, cursor, status
+    CREATE_TRY(dev_alloc(h, &scalars, 64));
+    c.work_count = scalars + 0; c.n_local = scalars + 8; c.n_local_next = scalars + 16; c.n_new = scalars + 24;
+    c.n_holes = scalars + 32; c.cursor = scalars + 40; c.status = scalars + 48;
+    CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
+    c.params = h->d_params;
+    CREATE_TRY(dev_alloc(h, &h->d_ctx, 1));
+    CREATE_TRY(hipHostMalloc((void **)&h->h_params, sizeof(FrameParams) * kParamRing, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 64, hipHostMallocDefault));
+    memset(h->h_scalars, 0, 64);
+    CREATE_TRY(hipMemcpyAsync(h->d_ctx, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i <= kNumStages; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
+    h->have_events = true;
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    (void)rc;
+    *out = h;
+    return DSM_OK;
+}
+
+void dsm_destroy(dsm_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++)
+        if (h->graph[i]) (void)hipGraphExecDestroy(h->graph[i]);
+    if (h->have_events)
+        for (int i = 0; i <= kNumStages; i++) (void)hipEventDestroy(h->ev[i]);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->h_params) (void)hipHostFree(h->h_params);
+    if (h->h_scalars) (void)hipHostFree(h->h_scalars);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int dsm_seed_count(const dsm_handle *h) { return h ? h->hc.n_seed : DSM_E_INVALID; }
+
+int dsm_stream(dsm_handle *h, void **hip_stream) {
+    if (!h || !hip_stream) return DSM_E_INVALID;
+    *hip_stream = (void *)h->stream;
+    return DSM_OK;
+}
+
+// ------------------------------------------------------------------ drop-in calls
+
+int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
+                            const float *depth, size_t depth_step, const float *pose16, dsm_surfel *local,
+                            int32_t n_local, dsm_surfel *new_out, int32_t new_cap, int32_t *n_new) {
+    if (!h) return DSM_E_INVALID;
+    if (!pose16 || !n_new || (new_cap > 0 && !new_out) || new_cap < 0) return fail(h, DSM_E_INVALID, "null/negative argument");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = upload_frame(h, 0, image, img_step, depth, depth_step, hipMemcpyHostToDevice))) return rc;
+    if ((rc = set_map(h, local, n_local))) return rc;
+    if ((rc = stage_params(h, 0, reference_frame_index, pose16))) return rc;
+    if ((rc = submit_frame(h, false))) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int k = h->h_scalars[1];
+    *n_new = k;
+    if (n_local) HIP_TRY(h, hipMemcpy(local, h->hc.local, (size_t)n_local * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    if (k > new_cap) return fail(h, DSM_E_CAPACITY, "%d new surfels exceed new_cap %d", k, new_cap);
+    if (k) HIP_TRY(h, hipMemcpy(new_out, h->hc.fresh, (size_t)k * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+
+int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step, const float *depth,
+                 size_t depth_step, const float *pose16, dsm_surfel *local, int32_t *n_local, int32_t cap,
+                 int32_t *n_new) {
+    if (!h) return DSM_E_INVALID;
+    if (!pose16 || !n_local || !n_new || cap < 0 || *n_local < 0 || *n_local > cap)
+        return fail(h, DSM_E_INVALID, "null/negative argument");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = upload_frame(h, 0, image, img_step, depth, depth_step, hipMemcpyHostToDevice))) return rc;
+    if ((rc = set_map(h, local, *n_local))) return rc;
+    if ((rc = stage_params(h, 0, reference_frame_index, pose16))) return rc;
+    if ((rc = submit_frame(h, true))) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    *n_new = h->h_scalars[1];
+    if (m > cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap);
+    if (m) HIP_TRY(h, hipMemcpy(local, h->hc.local, (size_t)m * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    *n_local = m;
+    return DSM_OK;
+}
+
+// ------------------------------------------------------------------ resident path
+
+int dsm_map_upload(dsm_handle *h, const dsm_surfel *surfels, int32_t n) {
+    if (!h) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    return set_map(h, surfels, n);
+}
+
+int dsm_map_size(dsm_handle *h, int32_t *n) {
+    if (!h || !n) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    *n = h->h_scalars[0];
+    return DSM_OK;
+}
+
+int dsm_map_download(dsm_handle *h, dsm_surfel *out, int32_t cap, int32_t *n) {
+    if (!h || !n || cap < 0) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    *n = m;
+    if (m > cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap);
+    if (m && !out) return fail(h, DSM_E_INVALID, "null output");
+    if (m) HIP_TRY(h, hipMemcpy(out, h->hc.local, (size_t)m * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+
+int dsm_map_copy_to_device(dsm_handle *h, void *dst_device, int32_t cap, int32_t *n) {
+    if (!h || !n || cap < 0) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    *n = m;
+    if (m > cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap);
+    if (m && !dst_device) return fail(h, DSM_E_INVALID, "null output");
+    if (m) HIP_TRY(h, hipMemcpy(dst_device, h->hc.local, (size_t)m * sizeof(dsm_surfel), hipMemcpyDeviceToDevice));
+    return DSM_OK;
+}
+
+int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
+                     size_t depth_step) {
+    if (!h) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = upload_frame(h, slot, image, img_step, depth, depth_step, hipMemcpyHostToDevice))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the caller may reuse its buffers
+    h->frames_done = h->frames_submitted;
+    return DSM_OK;
+}
+
+int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size_t img_step, const void *depth_dev,
+                            size_t depth_step) {
+    if (!h) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = upload_frame(h, slot, image_dev, img_step, depth_dev, depth_step, hipMemcpyDeviceToDevice))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->frames_done = h->frames_submitted;
+    return DSM_OK;
+}
+
+int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, const float *pose16) {
+    if (!h) return DSM_E_INVALID;
+    if (!pose16) return fail(h, DSM_E_INVALID, "null pose");
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = stage_params(h, slot, reference_frame_index, pose16))) return rc;
+    return submit_frame(h, true);
+}
+
+int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
+    if (!h) return DSM_E_INVALID;
+    if (n < 0 || (n > 0 && (!slots || !ref_idx || !poses16))) return fail(h, DSM_E_INVALID, "null/negative argument");
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        if ((rc = stage_params(h, slots[i], ref_idx[i], poses16 + 16 * (size_t)i))) return rc;
+        if ((rc = submit_frame(h, true))) return rc;
+    }
+    return DSM_OK;
+}
+
+int dsm_synchronize(dsm_handle *h) {
+    if (!h) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    return sync_and_fetch_counts(h);
+}
+
+int dsm_last_new_count(dsm_handle *h, int32_t *n_new) {
+    if (!h || !n_new) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    *n_new = h->h_scalars[1];
+    return DSM_OK;
+}
+
+// ------------------------------------------------------------------ taps
+
+int dsm_get_labels(dsm_handle *h, int32_t *out) {
+    if (!h || !out) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(out, (size_t)h->hc.w * 4, h->hc.label, (size_t)h->hc.pitch * 4, (size_t)h->hc.w * 4,
+                           (size_t)h->hc.h, hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+
+int dsm_get_seeds(dsm_handle *h, dsm_seed *out) {
+    if (!h || !out) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->hc.seeds, (size_t)h->hc.n_seed * sizeof(dsm_seed), hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+
+// ------------------------------------------------------------------ per-kernel timing
+
+int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
+                     dsm_stage_times *out) {
+    if (!h || !out) return DSM_E_INVALID;
+    if (n < 0 || (n > 0 && (!slots || !ref_idx || !poses16))) return fail(h, DSM_E_INVALID, "null/negative argument");
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    out->n_stages = kNumStages;
+    for (int s = 0; s < kNumStages; s++) {
+        out->name[s] = kStageNames[s];
+    }
+    for (int i = 0; i < n; i++) {
+        if ((rc = stage_params(h, slots[i], ref_idx[i], poses16 + 16 * (size_t)i))) return rc;
+        hipError_t e = launch_frame(h->d_ctx, h->hc, h->map_upper, true, h->stream, h->ev);
+        if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+        h->frames_submitted++;
+        if ((rc = sync_and_fetch_counts(h))) return rc;
+        for (int s = 0; s < kNumStages; s++) {
+            float ms = 0.0f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]));
+            out->ms[s] += (double)ms;
+            out->launches[s] += 1;
+        }
+        out->frames += 1;
+    }
+    return DSM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,79 @@
+// dsm_device.h -- device-resident state of one handle, shared by dsm_kernels.hip and dsm_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dsm.h"
+#include "dsm_math.h"
+
+namespace dsm {
+
+constexpr int kIntMax = 0x7fffffff;
+
+// Per-frame inputs that change from frame to frame.  A ring of these lives in HBM; kernels pick
+// entry (cursor % ring) so a captured hipGraph can be replayed without touching its arguments.
+struct FrameParams {
+    float pose[16]; // cam -> world, column-major
+    float inv[16];  // world -> cam (host-computed with inverse4<float>, FF.cpp:59)
+    int32_t ref_idx;
+    int32_t slot;
+    int32_t pad[2];
+};
+
+// Everything a kernel needs, in one struct in device memory (kernels take a single pointer).
+struct DeviceCtx {
+    // geometry
+    int32_t w, h, pitch; // pitch = row stride in elements of every image-shaped plane (multiple of 64)
+    int32_t gw, gh, n_seed;
+    Intrinsics k;
+    float far_d, near_d;
+    double huber, baseline, disp_err, min_tol;
+    // frame slots (HBM-resident inputs)
+    const uint8_t *img_base;
+    const float *depth_base;
+    int64_t slot_elems; // pitch * h
+    int32_t n_slots;
+    // superpixel state
+    int32_t *label; // [h][pitch] current superpixel index of every pixel
+    int32_t *cand;  // [h][pitch] seed picked by this sweep before the stable-skip rule is applied
+    float4 *core;   // [S] x, y, mean_intensity, mean_depth  (live seed state during the sweeps)
+    double *inv_depth; // [S] 1.0 / mean_depth, FF.cpp:380
+    float4 *core_stage; // [S] update_seeds output before the chunk-commit rule
+    int32_t *stable_stage;
+    // tmin[s]: -1 = seed unstable when the sweep started; INT_MAX = stable and never picked;
+    // otherwise the first pixel key (row-major) at which an evaluated pixel picked the seed.
+    int32_t *tmin;
+    int32_t *first_empty; // [kSweeps][kWorkers] first unstable seed without pixels, per worker chunk
+    int32_t *worklist;    // pixel keys whose old and new seeds were both stable at sweep start
+    int32_t *work_count;
+    dsm_seed *seeds; // [S] final seed table, reference layout
+    // surfel map
+    dsm_surfel *local;
+    int32_t cap;
+    dsm_surfel *fresh; // [S] surfels created by the current frame, seed order
+    int32_t *n_local;
+    int32_t *n_local_next;
+    int32_t *n_new;
+    uint64_t *hole_mask;  // [cap/64] bit i of word v: surfel 64v+i has update_times == 0
+    int32_t *wave_prefix; // [cap/64] exclusive prefix of popcounts
+    int32_t *holes;       // [cap] ascending indices of deleted slots
+    int32_t *n_holes;
+    // sequencing
+    const FrameParams *params;
+    int32_t n_params;
+    int32_t *cursor;
+    int32_t *status; // sticky device-side error bits
+};
+
+constexpr int kStatusCapacity = 1;
+constexpr int kStatusBadPick = 2;
+
+// launch all kernels of one frame on `stream`.  with_compaction: SurfelMap::fuse_map semantics,
+// otherwise FusionFunctions::fuse_initialize_map.  If ev != nullptr, an event is recorded before
+// the first kernel and after every kernel (ev[0..n_stages]).
+constexpr int kNumStages = 20;
+extern const char *const kStageNames[kNumStages];
+hipError_t launch_frame(const DeviceCtx *d_ctx, const DeviceCtx &h_ctx, int map_upper_bound, bool with_compaction,
+                        hipStream_t stream, hipEvent_t *ev);
+
+} // namespace dsm

@@ -1,0 +1,684 @@
+// dsm_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the per-frame surfel-fusion hot path.
+//
+// Reference functions covered ("FF.cpp" = surfel_fusion/src/fusion_functions.cpp, "SM.cpp" =
+// surfel_fusion/src/surfel_map.cpp of the reference):
+//   k_init_seeds    initialize_seeds_kernel          FF.cpp:577-629
+//   k_assign        update_pixels_kernel             FF.cpp:389-453 (+ calculate_cost 364-387)
+//   k_resolve/k_apply  the sequential `stable` skip rule of FF.cpp:400,445,450 as a fixed point
+//   k_update_seeds  update_seeds_kernel              FF.cpp:468-562
+//   k_commit_seeds  the early `return` of FF.cpp:516-517 (per worker chunk)
+//   k_seed_planes   calculate_spaces/pixels_norms/sp_depth_norms + get_huber_norm
+//                                                    FF.cpp:644-712, 792-914, 104-188
+//   k_fuse_surfels  fuse_surfels_kernel              FF.cpp:190-313
+//   k_new_surfels   initialize_surfels               FF.cpp:315-361
+//   k_hole_scan/k_compact  SurfelMap::fuse_map refill + swap-with-last   SM.cpp:1077-1109
+//
+// Build with -ffp-contract=off: results are required to match the CPU reference bit for bit.
+// The work is stencil / gather / ordered reduction -- HBM/L2 bound, no MFMA.
+#include "dsm_device.h"
+
+namespace dsm {
+
+// ------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+// number of set bits of m in lanes below mine
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// order LDS traffic of one wave: a lane's reads after this see every lane's writes before it
+// (the LDS queue of a wave is FIFO; this only stops the compiler from moving accesses across).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int load_coherent(const int32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) {
+    return c->params[(unsigned)c->cursor[0] % (unsigned)c->n_params];
+}
+__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &fp) {
+    return c->img_base + (int64_t)fp.slot * c->slot_elems;
+}
+__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &fp) {
+    return c->depth_base + (int64_t)fp.slot * c->slot_elems;
+}
+
+// ------------------------------------------------------------------------------ init seeds
+__global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx *__restrict__ c) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
+    if (s == 0) c->work_count[0] = 0;
+    if (s >= c->n_seed) return;
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    const int gx = s % c->gw, gy = s / c->gw;
+    int ix = gx * kCell + kCell / 2, iy = gy * kCell + kCell / 2;
+    if (ix > w - 1) ix = w - 1;
+    if (iy > h - 1) iy = h - 1;
+    float md = dep[iy * pitch + ix];
+    if ((double)md < 0.01) { // FF.cpp:600-626: first depth > 0.01 in the clipped window, row-major
+        int x0 = gx * kCell + kCell / 2 - kCell, y0 = gy * kCell + kCell / 2 - kCell;
+        int x1 = x0 + 2 * kCell, y1 = y0 + 2 * kCell;
+        if (x0 < 0) x0 = 0;
+        if (y0 < 0) y0 = 0;
+        if (x1 > w - 1) x1 = w - 1;
+        if (y1 > h - 1) y1 = h - 1;
+        bool found = false;
+        for (int y = y0; y < y1 && !found; y++)
+            for (int x = x0; x < x1; x++) {
+                float d = dep[y * pitch + x];
+                if ((double)d > 0.01) { md = d; found = true; break; }
+            }
+    }
+    c->core[s] = make_float4((float)ix, (float)iy, (float)img[iy * pitch + ix], md);
+    c->inv_depth[s] = 1.0 / (double)md;
+    c->tmin[s] = -1; // fused = stable = false
+}
+
+// ------------------------------------------------------------------------------ assign
+// One thread per pixel, 64x4-pixel tile per block; the <=10x3 seeds a tile can pick from are staged
+// in LDS.  FIRST sweep: every pixel is evaluated (all labels 0, seed 0 unstable) so the pick is the
+// label.  Later sweeps: the pick goes to `cand`, and the sequential skip rule is resolved through
+// tmin (see k_resolve).
+constexpr int kTileW = 64, kTileH = 4, kTileCellsX = kTileW / kCell + 2, kTileCellsY = 3;
+
+template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx *__restrict__ c) {
+    __shared__ float4 s_core[kTileCellsX * kTileCellsY];
+    __shared__ double s_inv[kTileCellsX * kTileCellsY];
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int w = c->w, h = c->h, pitch = c->pitch, gw = c->gw, gh = c->gh;
+    const int bx = blockIdx.x * kTileW, by = blockIdx.y * kTileH;
+    const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
+    const int tid = threadIdx.x;
+    if (tid < kTileCellsX * kTileCellsY) {
+        const int gx = cx0 + tid % kTileCellsX, gy = cy0 + tid / kTileCellsX;
+        if (gx >= 0 && gx < gw && gy >= 0 && gy < gh) {
+            s_core[tid] = c->core[gy * gw + gx];
+            s_inv[tid] = c->inv_depth[gy * gw + gx];
+        }
+    }
+    __syncthreads();
+    const int x = bx + (tid & (kTileW - 1)), y = by + tid / kTileW;
+    if (x >= w || y >= h) return;
+    const int p = y * pitch + x;
+    const float pix_i = (float)img[p];
+    const float pix_d = dep[p];
+    const int pick = pick_seed(x, y, pix_i, pix_d, gw, gh,
+                               [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
+                                   const int li = (gy - cy0) * kTileCellsX + (gx - cx0);
+                                   const float4 v = s_core[li];
+                                   sx = v.x; sy = v.y; si = v.z;
+                                   has_d = v.w > 0;
+                                   inv_d = s_inv[li];
+                               });
+    if (pick < 0) { // only for image sizes the reference itself mishandles; rejected by dsm_create
+        atomicOr(c->status, kStatusBadPick);
+        if (FIRST) c->label[p] = 0; else c->cand[p] = c->label[p];
+        return;
+    }
+    if (FIRST) {
+        c->label[p] = pick;
+        return;
+    }
+    c->cand[p] = pick;
+    const int l = c->label[p];
+    const int tl = c->tmin[l]; // -1 never changes; >= 0 only moves among values >= 0
+    if (tl == -1) {
+        // the old seed was unstable at sweep start: this pixel is evaluated whatever happens
+        // elsewhere, so its pick loses `stable` no later than at p
+        if (load_coherent(&c->tmin[pick]) > p) atomicMin(&c->tmin[pick], p);
+    } else if (pick != l && c->tmin[pick] != -1) {
+        // old and new seed both stable at sweep start: whether this pixel is evaluated depends on
+        // the scan order -- leave it to k_resolve
+        const int slot = atomicAdd(c->work_count, 1);
+        c->worklist[slot] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------ resolve
+// The reference scans pixels in row-major order; a pixel is skipped iff its current seed is still
+// `stable` when the scan reaches it, and every evaluated pixel clears `stable` of the seed it
+// picks.  With T[s] = first pixel key at which s is cleared this reads
+//     evaluated(p)  <=>  T[label(p)] < p ,      T[s] = min { p : evaluated(p), pick(p) = s } ,
+// whose least fixed point from above (T = -1 for unstable seeds, +inf for stable ones) is reached
+// by repeated atomicMin.  k_assign already applied every pixel whose seed was unstable; only the
+// pixels in the worklist can still change the picture.  One workgroup iterates them to the fixed
+// point (the list is short: borders between two seeds that both stopped moving).
+__global__ __launch_bounds__(1024) void k_resolve(const DeviceCtx *__restrict__ c) {
+    const int n = c->work_count[0];
+    if (n == 0) return;
+    for (;;) {
+        int changed = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int p = c->worklist[i];
+            const int l = c->label[p], pk = c->cand[p];
+            if (load_coherent(&c->tmin[l]) < p && load_coherent(&c->tmin[pk]) > p) {
+                atomicMin(&c->tmin[pk], p);
+                changed = 1;
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_apply(const DeviceCtx *__restrict__ c) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= c->w) return;
+    const int p = y * c->pitch + x;
+    const int l = c->label[p];
+    if (c->tmin[l] < p) c->label[p] = c->cand[p];
+}
+
+// ------------------------------------------------------------------------------ update seeds
+// One wave per seed.  Lanes cover the 16x16 window (4 pixels each, row-major across k*64+lane).
+// Counts and coordinate/intensity sums are integers (exact in the reference's fp32 accumulators,
+// any order); the depth sum and the Huber-Newton passes are fp32 sums in window row-major order,
+// so member depths are compacted in order into LDS and summed sequentially.
+constexpr int kWin = 2 * kCell; // 16
+
+__global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restrict__ c, int sweep) {
+    __shared__ float s_depth[4][kWin * kWin];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int s = blockIdx.x * 4 + wv;
+    if (s >= c->n_seed) return;
+    if (c->tmin[s] == kIntMax) return; // stable: FF.cpp:479-480
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
+    float *dl = s_depth[wv];
+    int cnt = 0, sx = 0, sy = 0, si = 0, nd = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        // window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
+        const bool in = x >= 0 && x < w - 1 && y >= 0 && y < h - 1;
+        const int p = y * pitch + x;
+        const bool mem = in && c->label[p] == s;
+        float d = 0.0f;
+        if (mem) {
+            d = dep[p];
+            cnt += 1; sx += x; sy += y; si += (int)img[p];
+        }
+        const bool dv = mem && (double)d > 0.1; // FF.cpp:508
+        const unsigned long long m = __ballot(dv);
+        if (dv) dl[nd + rank_below(m)] = d;
+        nd += __popcll(m);
+    }
+    cnt = wave_sum(cnt);
+    if (cnt == 0) { // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
+        if (lane == 0) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(c->n_seed, s)], s);
+        return;
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); si = wave_sum(si);
+    wave_lds_sync();
+    const float fn = (float)cnt;
+    const float mi = (float)si / fn, mx = (float)sx / fn, my = (float)sy / fn;
+    const float4 old = c->core[s];
+    const float moved = fabsf(old.z - mi) + fabsf(old.x - mx) + fabsf(old.y - my);
+    const int stable = (double)moved < 0.2 ? 1 : 0;
+    float md = 0.0f;
+    if (nd > 0) {
+        float sum = 0.0f;
+        for (int i = 0; i < nd; i++) sum += dl[i];
+        md = huber_mean_depth(dl, nd, sum, c->huber);
+    }
+    if (lane == 0) {
+        c->core_stage[s] = make_float4(mx, my, mi, md);
+        c->stable_stage[s] = stable;
+    }
+}
+
+// Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
+__global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx *__restrict__ c, int sweep) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) c->work_count[0] = 0;
+    if (s >= c->n_seed) return;
+    if (c->tmin[s] == kIntMax) return;
+    int t = -1;
+    if (s < c->first_empty[sweep * kWorkers + chunk_of(c->n_seed, s)]) {
+        const float4 v = c->core_stage[s];
+        c->core[s] = v;
+        c->inv_depth[s] = 1.0 / (double)v.w;
+        if (c->stable_stage[s]) t = kIntMax;
+    }
+    c->tmin[s] = t;
+}
+
+// ------------------------------------------------------------------------------ seed planes
+// One wave per seed: gather the member pixels with valid depth (window row-major order), keep the
+// depth inliers, average their forward-difference normals, refine a plane by 5 Huber-weighted
+// Gauss-Newton steps and derive position / view angle / size.  Back-projections and pixel normals
+// are recomputed from the depth plane (the reference's 36 B/pixel space_map and norm_map never
+// exist in memory).  All order-sensitive sums run in the reference's order; the 20 double
+// accumulators of a Gauss-Newton step are independent, so 20 lanes each carry one.
+__global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict__ c) {
+    __shared__ float s_d[4][kWin * kWin];
+    __shared__ int s_xy[4][kWin * kWin];
+    __shared__ float s_n[4][kWin * kWin * 3];
+    __shared__ float s_p[4][kWin * kWin * 3];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int s = blockIdx.x * 4 + wv;
+    if (s >= c->n_seed) return;
+    const FrameParams &fp = frame_params(c);
+    const float *dep = frame_depth(c, fp);
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    const Intrinsics K = c->k;
+    const double hr = c->huber;
+    const float4 core = c->core[s];
+    const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
+    float *ld = s_d[wv], *ln = s_n[wv], *lp = s_p[wv];
+    int *lxy = s_xy[wv];
+
+    // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
+    int n = 0;
+    float far2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        const bool in = x >= 0 && x < w && y >= 0 && y < h;
+        const int p = y * pitch + x;
+        const bool mem = in && c->label[p] == s;
+        float d = 0.0f;
+        if (mem) {
+            d = dep[p];
+            const float ex = (float)x - core.x, ey = (float)y - core.y;
+            const float d2 = ex * ex + ey * ey;
+            if (d2 > far2) far2 = d2;
+        }
+        const bool ok = mem && (double)d > 0.05;
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const int pos = n + rank_below(m);
+            ld[pos] = d;
+            lxy[pos] = x | (y << 16);
+        }
+        n += __popcll(m);
+    }
+    far2 = wave_max(far2);
+    wave_lds_sync();
+
+    dsm_seed out;
+    out.x = core.x; out.y = core.y;
+    out.size = 0; out.norm_x = out.norm_y = out.norm_z = 0;
+    out.posi_x = out.posi_y = out.posi_z = 0;
+    out.view_cos = 0;
+    out.mean_depth = core.w;
+    out.mean_intensity = core.z;
+    out.fused = 0;
+    out.stable = c->tmin[s] == kIntMax ? 1 : 0;
+    out.pad_[0] = out.pad_[1] = 0;
+    out.min_eigen_value = out.max_eigen_value = 0;
+
+    bool fitted = false;
+    if (n >= 16) { // FF.cpp:841
+        // ---- depth inliers: their pixel normals and back-projected points, in order (FF.cpp:846-861)
+        const float md = core.w;
+        int m_in = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool ok = false;
+            float d = 0.0f;
+            int x = 0, y = 0;
+            if (i < n) {
+                d = ld[i];
+                const int xy = lxy[i];
+                x = xy & 0xffff; y = xy >> 16;
+                const float r = md - d;
+                ok = (double)r < hr && (double)r > -hr;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = m_in + rank_below(m);
+                float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+                if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) // FF.cpp:670-677
+                    pixel_normal(K, x, y, d, dep[y * pitch + x + 1], dep[(y + 1) * pitch + x], nx, ny, nz);
+                ln[pos * 3] = nx; ln[pos * 3 + 1] = ny; ln[pos * 3 + 2] = nz;
+                float px, py, pz;
+                back_project(K, (float)x, (float)y, d, px, py, pz);
+                lp[pos * 3] = px; lp[pos * 3 + 1] = py; lp[pos * 3 + 2] = pz;
+            }
+            m_in += __popcll(m);
+        }
+        wave_lds_sync();
+        if (!((double)((float)m_in / (float)n) < 0.8)) { // FF.cpp:862
+            float nx = 0, ny = 0, nz = 0, nb = 0;
+            float mx = 0, my = 0, mz = 0;
+            for (int i = 0; i < m_in; i++) { // sequential fp32 sums, FF.cpp:852-857 and 111-116
+                nx += ln[i * 3]; ny += ln[i * 3 + 1]; nz += ln[i * 3 + 2];
+                mx += lp[i * 3]; my += lp[i * 3 + 1]; mz += lp[i * 3 + 2];
+            }
+            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            nx = nx / len; ny = ny / len; nz = nz / len;
+            mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
+            wave_lds_sync();
+            for (int i = lane; i < m_in; i += 64) { // centre the points, FF.cpp:121-126
+                lp[i * 3] -= mx; lp[i * 3 + 1] -= my; lp[i * 3 + 2] -= mz;
+            }
+            wave_lds_sync();
+            // lanes 0..15: Hessian entry (a = lane & 3, b = lane >> 2); lanes 16..19: Jacobian entry
+            GnTerm term;
+            term.a = lane < 16 ? (lane & 3) : ((lane - 16) & 3);
+            term.b = lane < 16 ? (lane >> 2) : -1;
+            const bool carries = lane < 20;
+            for (int it = 0; it < 5; it++) {
+                double acc = 0.0;
+                for (int i = 0; i < m_in; i++) {
+                    float p4[4] = {lp[i * 3], lp[i * 3 + 1], lp[i * 3 + 2], 1.0f};
+                    const float r = p4[0] * nx + p4[1] * ny + p4[2] * nz + nb;
+                    if (carries) acc = gn_term_add(acc, term, p4, r, hr);
+                }
+                double H[16], J[4];
+#pragma unroll
+                for (int e = 0; e < 16; e++) H[e] = __shfl(acc, e); // H[col*4+row]: a = row, b = col
+#pragma unroll
+                for (int e = 0; e < 4; e++) J[e] = __shfl(acc, 16 + e);
+                gn_step(H, J, nx, ny, nz, nb);
+            }
+            plane_finish(nx, ny, nz, nb, mx, my, mz);
+            const SeedGeom g = seed_geometry(K, core.x, core.y, md, nx, ny, nz, nb);
+            out.norm_x = g.nx; out.norm_y = g.ny; out.norm_z = g.nz;
+            out.posi_x = g.px; out.posi_y = g.py; out.posi_z = g.pz;
+            out.mean_depth = g.mean_depth;
+            out.view_cos = g.view_cos;
+            out.size = sqrtf(far2);
+            fitted = true;
+        }
+    }
+    (void)fitted;
+    if (lane == 0) c->seeds[s] = out;
+}
+
+// ------------------------------------------------------------------------------ fuse surfels
+// One lane per surfel, a wave per 64 consecutive surfels (so the deleted-slot bitmap is one ballot).
+// Pure gather: a surfel reads one depth pixel, one label and one seed and rewrites only itself;
+// the single shared write is the idempotent `fused` byte of the seed.
+__global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx *__restrict__ c) {
+    const FrameParams &fp = frame_params(c);
+    const float *dep = frame_depth(c, fp);
+    const int M = c->n_local[0];
+    const int n_wave = (M + 63) >> 6;
+    const int lane = lane_id();
+    FuseConst fc;
+    fc.k = c->k; fc.far_d = c->far_d; fc.near_d = c->near_d;
+    fc.baseline = c->baseline; fc.disp_err = c->disp_err; fc.min_tol = c->min_tol;
+    fc.w = c->w; fc.h = c->h;
+    const int ref_idx = fp.ref_idx;
+    const int waves_total = (gridDim.x * 256) >> 6;
+    for (int wv = (blockIdx.x * 256 + threadIdx.x) >> 6; wv < n_wave; wv += waves_total) {
+        const int i = wv * 64 + lane;
+        bool hole = false;
+        if (i < M) {
+            const dsm_surfel raw = c->local[i];
+            Surfel e;
+            e.px = raw.px; e.py = raw.py; e.pz = raw.pz; e.nx = raw.nx; e.ny = raw.ny; e.nz = raw.nz;
+            e.size = raw.size; e.color = raw.color; e.weight = raw.weight;
+            e.update_times = raw.update_times; e.last_update = raw.last_update;
+            int ui, vi;
+            float pc[3], nc[3];
+            FuseOutcome oc = fuse_project(fc, ref_idx, fp.inv, e, ui, vi, pc, nc);
+            if (oc == kFuseNeedPixel) {
+                const int p = vi * c->pitch + ui;
+                const int sidx = c->label[p];
+                const dsm_seed *sp = &c->seeds[sidx];
+                SeedView sd;
+                sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
+                sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
+                sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+                oc = fuse_update(fc, ref_idx, fp.pose, e, pc, nc, dep[p], sd);
+                if (oc == kFuseFused) c->seeds[sidx].fused = 1;
+            }
+            if (oc == kFuseDeleted) {
+                c->local[i].update_times = 0;
+            } else if (oc == kFuseFused) {
+                dsm_surfel o;
+                o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
+                o.size = e.size; o.color = e.color; o.weight = e.weight;
+                o.update_times = e.update_times; o.last_update = e.last_update;
+                c->local[i] = o;
+            }
+            hole = e.update_times == 0;
+        }
+        const unsigned long long m = __ballot(hole);
+        if (lane == 0) c->hole_mask[wv] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------ block scan helper
+// exclusive prefix sum of one int per thread over a 1024-thread block; returns the block total
+__device__ __forceinline__ int block_scan_1024(int v, int &excl, int *s_wave /* [17] */) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads(); // s_wave reuse across calls
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 16; i++) { const int t = s_wave[i]; s_wave[i] = run; run += t; }
+        s_wave[16] = run;
+    }
+    __syncthreads();
+    excl = s_wave[wv] + inc - v;
+    return s_wave[16];
+}
+
+// ------------------------------------------------------------------------------ new surfels
+// initialize_surfels: seeds in index order -> ordered stream compaction by one workgroup.
+__global__ __launch_bounds__(1024) void k_new_surfels(const DeviceCtx *__restrict__ c) {
+    __shared__ int s_wave[17];
+    const FrameParams &fp = frame_params(c);
+    const Intrinsics K = c->k;
+    int run = 0;
+    for (int base = 0; base < c->n_seed; base += 1024) {
+        const int s = base + threadIdx.x;
+        bool spawn = false;
+        SeedView sd;
+        if (s < c->n_seed) {
+            const dsm_seed *sp = &c->seeds[s];
+            sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
+            sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
+            sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+            spawn = seed_spawns(sd, sp->fused != 0);
+        }
+        int excl;
+        const int total = block_scan_1024(spawn ? 1 : 0, excl, s_wave);
+        if (spawn) {
+            const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
+            dsm_surfel o;
+            o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
+            o.size = e.size; o.color = e.color; o.weight = e.weight;
+            o.update_times = e.update_times; o.last_update = e.last_update;
+            c->fresh[run + excl] = o;
+        }
+        run += total;
+    }
+    if (threadIdx.x == 0) c->n_new[0] = run;
+}
+
+// ------------------------------------------------------------------------------ hole scan
+// Ascending list of deleted slots (SM.cpp:1078-1083) from the per-wave bitmaps.
+__global__ __launch_bounds__(1024) void k_hole_scan(const DeviceCtx *__restrict__ c) {
+    __shared__ int s_wave[17];
+    const int M = c->n_local[0];
+    const int n_word = (M + 63) >> 6;
+    int run = 0;
+    for (int base = 0; base < n_word; base += 1024) {
+        const int v = base + threadIdx.x;
+        unsigned long long m = 0;
+        if (v < n_word) m = c->hole_mask[v];
+        int excl;
+        const int total = block_scan_1024(__popcll(m), excl, s_wave);
+        if (v < n_word) {
+            int o = run + excl;
+            c->wave_prefix[v] = o;
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                c->holes[o++] = v * 64 + b;
+                m &= m - 1;
+            }
+        }
+        run += total;
+    }
+    if (threadIdx.x == 0) c->n_holes[0] = run;
+}
+
+// ------------------------------------------------------------------------------ compaction
+// SM.cpp:1087-1109 in parallel-exact form.  D = holes ascending (k of them), K new surfels.
+//   new j          -> D[k-1-j] while j < k, else appended in order;
+//   if K < k, the r = k-K smallest holes remain.  Taken in descending order H[i] = D[r-1-i], step i
+//   copies the element at index M-1-i (the then-last element) into H[i] and shrinks the array.  A
+//   source index that is itself a remaining hole H[j] (j < i) was overwritten in step j by the
+//   element at M-1-j: follow that chain to a live element.  Targets >= M-r are cut off anyway.
+// Every target is written by exactly one thread and no thread reads a slot another one writes
+// (sources are live slots >= M-r or entries of `fresh`), so the copy is done in place.
+__device__ __forceinline__ bool is_hole(const DeviceCtx *c, int i, int &rank) {
+    const unsigned long long m = c->hole_mask[i >> 6];
+    const int b = i & 63;
+    rank = c->wave_prefix[i >> 6] + __popcll(m & ((1ull << b) - 1ull));
+    return (m >> b) & 1ull;
+}
+
+__global__ __launch_bounds__(256) void k_compact(const DeviceCtx *__restrict__ c) {
+    const int M = c->n_local[0], K = c->n_new[0], k = c->n_holes[0];
+    const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    dsm_surfel *local = c->local;
+    const dsm_surfel *fresh = c->fresh;
+    int new_m;
+    if (K >= k) {
+        new_m = M + (K - k);
+        if (new_m > c->cap) { // cannot append: report, keep what fits
+            if (tid == 0) atomicOr(c->status, kStatusCapacity);
+            new_m = c->cap;
+        }
+        for (int j = tid; j < K; j += nthr) {
+            const int tgt = j < k ? c->holes[k - 1 - j] : M + (j - k);
+            if (tgt < c->cap) local[tgt] = fresh[j];
+        }
+    } else {
+        const int r = k - K, cut = M - r;
+        new_m = cut;
+        for (int j = tid; j < K; j += nthr) local[c->holes[k - 1 - j]] = fresh[j];
+        for (int i = tid; i < r; i += nthr) {
+            const int tgt = c->holes[r - 1 - i];
+            if (tgt >= cut) continue;
+            int src = M - 1 - i, rank;
+            bool hole;
+            while ((hole = is_hole(c, src, rank)) && rank < r) src = M - 1 - (r - 1 - rank);
+            local[tgt] = hole ? fresh[k - 1 - rank] : local[src];
+        }
+    }
+    if (tid == 0) c->n_local_next[0] = new_m;
+}
+
+// advance to the next frame: commit the map size, bump the params cursor
+__global__ void k_end_frame(const DeviceCtx *__restrict__ c, int with_compaction) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (with_compaction) c->n_local[0] = c->n_local_next[0];
+        c->cursor[0] = c->cursor[0] + 1;
+    }
+}
+
+// Timed replays only: keep the GPU busy for `ticks` of the 100 MHz wall clock while the host enqueues
+// the whole frame, so that the events between kernels do not measure host launch latency.
+__global__ void k_delay(long long ticks) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < 2000000; i++) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// ------------------------------------------------------------------------------ launcher
+const char *const kStageNames[kNumStages] = {
+    "init_seeds",   "assign_0",  "update_seeds_0", "commit_seeds_0", "assign_1",     "resolve_1",  "apply_1",
+    "update_seeds_1", "commit_seeds_1", "assign_2", "resolve_2",     "apply_2",      "update_seeds_2", "commit_seeds_2",
+    "seed_planes",  "fuse_surfels", "new_surfels", "hole_scan",      "compact",      "end_frame",
+};
+
+hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
+                        hipStream_t st, hipEvent_t *ev) {
+    int stage = 0;
+    hipError_t err = hipSuccess;
+#define DSM_MARK()                                                                      \
+    do {                                                                                \
+        if (ev) {                                                                       \
+            err = hipEventRecord(ev[stage], st);                                        \
+            if (err != hipSuccess) return err;                                          \
+        }                                                                               \
+        stage++;                                                                        \
+    } while (0)
+    const int S = hc.n_seed;
+    const dim3 g_seed_thr((S + 255) / 256), g_seed_wave((S + 3) / 4);
+    const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
+    const dim3 g_row((hc.w + 255) / 256, hc.h);
+    if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
+    DSM_MARK();
+    hipLaunchKernelGGL(k_init_seeds, g_seed_thr, dim3(256), 0, st, d);
+    DSM_MARK();
+    for (int sweep = 0; sweep < kSweeps; sweep++) {
+        if (sweep == 0) {
+            hipLaunchKernelGGL(k_assign<true>, g_tile, dim3(256), 0, st, d);
+            DSM_MARK();
+        } else {
+            hipLaunchKernelGGL(k_assign<false>, g_tile, dim3(256), 0, st, d);
+            DSM_MARK();
+            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, st, d);
+            DSM_MARK();
+            hipLaunchKernelGGL(k_apply, g_row, dim3(256), 0, st, d);
+            DSM_MARK();
+        }
+        hipLaunchKernelGGL(k_update_seeds, g_seed_wave, dim3(256), 0, st, d, sweep);
+        DSM_MARK();
+        hipLaunchKernelGGL(k_commit_seeds, g_seed_thr, dim3(256), 0, st, d, sweep);
+        DSM_MARK();
+    }
+    hipLaunchKernelGGL(k_seed_planes, g_seed_wave, dim3(256), 0, st, d);
+    DSM_MARK();
+    int fuse_blocks = (map_upper_bound + 255) / 256;
+    if (fuse_blocks < 1) fuse_blocks = 1;
+    if (fuse_blocks > 2048) fuse_blocks = 2048;
+    hipLaunchKernelGGL(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, d);
+    DSM_MARK();
+    hipLaunchKernelGGL(k_new_surfels, dim3(1), dim3(1024), 0, st, d);
+    DSM_MARK();
+    if (with_compaction) {
+        hipLaunchKernelGGL(k_hole_scan, dim3(1), dim3(1024), 0, st, d);
+        DSM_MARK();
+        hipLaunchKernelGGL(k_compact, dim3(64), dim3(256), 0, st, d);
+        DSM_MARK();
+    } else {
+        DSM_MARK();
+        DSM_MARK();
+    }
+    hipLaunchKernelGGL(k_end_frame, dim3(1), dim3(64), 0, st, d, with_compaction ? 1 : 0);
+    DSM_MARK();
+#undef DSM_MARK
+    return hipGetLastError();
+}
+
+} // namespace dsm

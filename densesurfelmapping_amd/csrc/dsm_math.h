@@ -1,0 +1,363 @@
+// dsm_math.h -- the per-element arithmetic of the surfel-fusion hot path, written once and used
+// by every HIP kernel in dsm_kernels.hip (and, compiled for the host, by tests/hostemu.cpp,
+// which checks it against the oracle without a GPU).
+//
+// Every expression is typed exactly as the reference's C++ evaluates it (usual arithmetic
+// conversions, double literals, no FMA): the translation unit must be built with
+// -ffp-contract=off and hipcc's default correctly-rounded fp32 divide/sqrt.
+// "FF.cpp" = surfel_fusion/src/fusion_functions.cpp of the reference.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define DSM_HD __host__ __device__ __forceinline__
+#else
+#define DSM_HD static inline
+#endif
+
+namespace dsm {
+
+constexpr int kCell = 8;          // SP_SIZE        fusion_functions.h:10
+constexpr int kSweeps = 3;        // ITERATION_NUM  fusion_functions.h:8
+constexpr int kWorkers = 10;      // THREAD_NUM     fusion_functions.h:9
+constexpr double kAngleCos = 0.1; // MAX_ANGLE_COS  fusion_functions.h:11
+
+struct Intrinsics {
+    float fx, fy, cx, cy;
+};
+
+// ---------------------------------------------------------------- SLIC cost, FF.cpp:364-387
+// Seed side: x, y, mean intensity, and the double 1.0/mean_depth (valid iff has_depth).
+// Returns whether the depth term applied.
+DSM_HD bool pixel_cost(float sx, float sy, float si, bool seed_has_depth, double seed_inv_depth, float pix_i,
+                       float pix_invd, int x, int y, float &no_d, float &with_d) {
+    float ddx = sx - (float)x, ddy = sy - (float)y;
+    float dist = ddx * ddx + ddy * ddy;
+    float cost = 0.0f;
+    cost += dist / (float)((kCell / 2) * (kCell / 2));
+    float di = si - pix_i;
+    cost = (float)((double)cost + (double)(di * di) / 100.0); // FF.cpp:376
+    no_d = cost;
+    with_d = cost;
+    if (seed_has_depth && pix_invd > 0) {
+        float dd = (float)(seed_inv_depth - (double)pix_invd);      // FF.cpp:380
+        with_d = (float)((double)cost + (double)(dd * dd) * 400.0); // FF.cpp:381
+        return true;
+    }
+    return false;
+}
+
+// inverse depth of a pixel, FF.cpp:404-405
+DSM_HD float pixel_inv_depth(float d) {
+    float invd = 0.0f;
+    if ((double)d > 0.01) invd = (float)(1.0 / (double)d);
+    return invd;
+}
+
+// Pick the seed of pixel (x,y): candidates are the <=2x2 in-grid cells whose centre is closer
+// than one cell in both axes, visited x-offset outer / y-offset inner, strict '<' (FF.cpp:413-451).
+// load(gx, gy, sx, sy, si, has_depth, inv_depth) fetches the cost-side state of grid cell (gx,gy).
+template <typename LoadSeed>
+DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeed load) {
+    const float invd = pixel_inv_depth(pix_d);
+    const int bx = x / kCell, by = y / kCell;
+    float best_d = 1e6f, best_n = 1e6f;
+    int arg_d = -1, arg_n = -1;
+    bool all_depth = true;
+    for (int ox = -1; ox <= 1; ox++) {
+        const int gx = bx + ox;
+        int ax = gx * kCell + kCell / 2 - x;
+        ax = ax < 0 ? -ax : ax;
+        if (!(ax < kCell && gx >= 0 && gx < gw)) continue;
+        for (int oy = -1; oy <= 1; oy++) {
+            const int gy = by + oy;
+            int ay = gy * kCell + kCell / 2 - y;
+            ay = ay < 0 ? -ay : ay;
+            if (!(ay < kCell && gy >= 0 && gy < gh)) continue;
+            const int s = gy * gw + gx;
+            float sx, sy, si;
+            bool has_d;
+            double inv_d;
+            load(gx, gy, sx, sy, si, has_d, inv_d);
+            float cn, cd;
+            const bool with = pixel_cost(sx, sy, si, has_d, inv_d, pix_i, invd, x, y, cn, cd);
+            all_depth = all_depth && with;
+            if (cd < best_d) { best_d = cd; arg_d = s; }
+            if (cn < best_n) { best_n = cn; arg_n = s; }
+        }
+    }
+    return all_depth ? arg_d : arg_n; // FF.cpp:442-451
+}
+
+// ------------------------------------------------- robust mean depth of a seed, FF.cpp:530-556
+// list[0..n) = member depths > 0.1 in window row-major order, sum = their sequential fp32 sum.
+DSM_HD float huber_mean_depth(const float *list, int n, float sum, double huber) {
+    float md = sum / (float)n;
+    for (int it = 0; it < 5; it++) {
+        float a = 0, b = 0;
+        for (int k = 0; k < n; k++) {
+            float r = md - list[k];
+            if ((double)r < huber && (double)r > -huber) {
+                a += 2 * r;
+                b += 2;
+            } else {
+                a = (float)((double)a + (r > 0 ? huber : -1 * huber));
+            }
+        }
+        float delta = (float)((double)(-a) / ((double)b + 10.0));
+        md = md + delta;
+        if ((double)delta < 0.01 && (double)delta > -0.01) break;
+    }
+    return md;
+}
+
+// ------------------------------------------------------------- back-projection, FF.cpp:91-97
+DSM_HD void back_project(const Intrinsics &k, float u, float v, float d, float &x, float &y, float &z) {
+    x = (u - k.cx) / k.fx * d;
+    y = (v - k.cy) / k.fy * d;
+    z = d;
+}
+
+// per-pixel normal from forward differences, FF.cpp:664-712.  Caller guarantees
+// 1 <= x <= w-2 and 1 <= y <= h-2; returns false (normal stays 0) when rejected.
+DSM_HD bool pixel_normal(const Intrinsics &k, int x, int y, float d, float d_right, float d_down, float &nx,
+                         float &ny, float &nz) {
+    if ((double)d < 0.1 || (double)d_right < 0.1 || (double)d_down < 0.1) return false;
+    float px, py, pz, rx, ry, rz, dx, dy, dz;
+    back_project(k, (float)x, (float)y, d, px, py, pz);
+    back_project(k, (float)(x + 1), (float)y, d_right, rx, ry, rz);
+    back_project(k, (float)x, (float)(y + 1), d_down, dx, dy, dz);
+    rx = rx - px; ry = ry - py; rz = rz - pz;
+    dx = dx - px; dy = dy - py; dz = dz - pz;
+    float ax = ry * dz - rz * dy, ay = rz * dx - rx * dz, az = rx * dy - ry * dx;
+    float len = sqrtf(ax * ax + ay * ay + az * az);
+    ax /= len; ay /= len; az /= len;
+    float va = (ax * px + ay * py + az * pz) / sqrtf(px * px + py * py + pz * pz);
+    if ((double)va > -kAngleCos && (double)va < kAngleCos) return false;
+    nx = ax; ny = ay; nz = az;
+    return true;
+}
+
+// -------------------------------------- general 4x4 inverse, column-major, adjugate / determinant
+// (stands in for Eigen's Matrix4::inverse at FF.cpp:59 and FF.cpp:176; same closed form and
+// operation order as the oracle's Eigen shim).
+template <typename T> DSM_HD void inverse4(const T *a, T *o) {
+    T s0 = a[0] * a[5] - a[1] * a[4], s1 = a[0] * a[9] - a[1] * a[8], s2 = a[0] * a[13] - a[1] * a[12];
+    T s3 = a[4] * a[9] - a[5] * a[8], s4 = a[4] * a[13] - a[5] * a[12], s5 = a[8] * a[13] - a[9] * a[12];
+    T c5 = a[10] * a[15] - a[11] * a[14], c4 = a[6] * a[15] - a[7] * a[14], c3 = a[6] * a[11] - a[7] * a[10];
+    T c2 = a[2] * a[15] - a[3] * a[14], c1 = a[2] * a[11] - a[3] * a[10], c0 = a[2] * a[7] - a[3] * a[6];
+    T det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    T id = (T)1 / det;
+    o[0] = (a[5] * c5 - a[9] * c4 + a[13] * c3) * id;
+    o[4] = (-a[4] * c5 + a[8] * c4 - a[12] * c3) * id;
+    o[8] = (a[7] * s5 - a[11] * s4 + a[15] * s3) * id;
+    o[12] = (-a[6] * s5 + a[10] * s4 - a[14] * s3) * id;
+    o[1] = (-a[1] * c5 + a[9] * c2 - a[13] * c1) * id;
+    o[5] = (a[0] * c5 - a[8] * c2 + a[12] * c1) * id;
+    o[9] = (-a[3] * s5 + a[11] * s2 - a[15] * s1) * id;
+    o[13] = (a[2] * s5 - a[10] * s2 + a[14] * s1) * id;
+    o[2] = (a[1] * c4 - a[5] * c2 + a[13] * c0) * id;
+    o[6] = (-a[0] * c4 + a[4] * c2 - a[12] * c0) * id;
+    o[10] = (a[3] * s4 - a[7] * s2 + a[15] * s0) * id;
+    o[14] = (-a[2] * s4 + a[6] * s2 - a[14] * s0) * id;
+    o[3] = (-a[1] * c3 + a[5] * c1 - a[9] * c0) * id;
+    o[7] = (a[0] * c3 - a[4] * c1 + a[8] * c0) * id;
+    o[11] = (-a[3] * s3 + a[7] * s1 - a[11] * s0) * id;
+    o[15] = (a[2] * s3 - a[6] * s1 + a[10] * s0) * id;
+}
+
+// One Gauss-Newton accumulator of get_huber_norm (FF.cpp:129-170).  The 16 Hessian entries and
+// the 4 Jacobian entries are independent sequential double sums; with the homogeneous point
+// p = (p0,p1,p2,1) they are  H(a,b) += (double)(2*p_a*p_b)  and  J(a) += (double)(2*r*p_a)  in
+// the Huber core and  J(a) += +-hr*(double)p_a  in the tails (multiplying by 1.0f is exact, so
+// the reference's special-cased last row/column give the same bits).
+struct GnTerm {
+    int a, b;  // b < 0: Jacobian entry a
+};
+DSM_HD double gn_term_add(double acc, const GnTerm &t, const float p[4], float r, double hr) {
+    const float pa = p[t.a];
+    if ((double)r < hr && (double)r > -1 * hr) {
+        if (t.b < 0) return acc + (double)(2 * r * pa);
+        return acc + (double)(2 * pa * p[t.b]);
+    } else if ((double)r >= hr) {
+        if (t.b < 0) return acc + hr * (double)pa;
+    } else if ((double)r <= -1 * hr) {
+        if (t.b < 0) return acc + -1 * hr * (double)pa;
+    }
+    return acc;
+}
+
+// solve and apply one Gauss-Newton step, FF.cpp:172-180.  H column-major 4x4 (without damping).
+DSM_HD void gn_step(double *H, const double *J, float &nx, float &ny, float &nz, float &nb) {
+    H[0] += 5; H[5] += 5; H[10] += 5; H[15] += 5;
+    double Hi[16];
+    inverse4<double>(H, Hi);
+    double u[4];
+    for (int i = 0; i < 4; i++) u[i] = ((Hi[i] * J[0] + Hi[4 + i] * J[1]) + Hi[8 + i] * J[2]) + Hi[12 + i] * J[3];
+    nx = (float)((double)nx - u[0]);
+    ny = (float)((double)ny - u[1]);
+    nz = (float)((double)nz - u[2]);
+    nb = (float)((double)nb - u[3]);
+}
+
+// tail of get_huber_norm, FF.cpp:182-187
+DSM_HD void plane_finish(float &nx, float &ny, float &nz, float &nb, float mx, float my, float mz) {
+    nb = nb - (nx * mx + ny * my + nz * mz);
+    float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    nx /= len; ny /= len; nz /= len; nb /= len;
+}
+
+// Seed geometry after the plane fit, FF.cpp:884-912.
+struct SeedGeom {
+    float nx, ny, nz, px, py, pz, view_cos, mean_depth;
+};
+DSM_HD SeedGeom seed_geometry(const Intrinsics &k, float seed_x, float seed_y, float md, float nx, float ny, float nz,
+                              float nb) {
+    float bx, by, bz;
+    back_project(k, seed_x, seed_y, md, bx, by, bz);
+    double ax = bx, ay = by, az = bz;
+    float kk = (float)(-1 * (ax * (double)nx + ay * (double)ny + az * (double)nz) - (double)nb); // FF.cpp:890
+    ax += (double)(kk * nx); ay += (double)(kk * ny); az += (double)(kk * nz);
+    md = (float)az;
+    float vc = (float)(-1.0 * ((double)nx * ax + (double)ny * ay + (double)nz * az) / sqrt(ax * ax + ay * ay + az * az));
+    if (vc < 0) { vc = -vc; nx = -nx; ny = -ny; nz = -nz; }
+    SeedGeom g;
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    g.px = (float)ax; g.py = (float)ay; g.pz = (float)az;
+    g.view_cos = vc; g.mean_depth = md;
+    return g;
+}
+
+// ------------------------------------------------------------------ rigid transforms, FF.cpp:220,228
+DSM_HD void xform_point(const float *m, const float *p, float *o) {
+    for (int i = 0; i < 3; i++) o[i] = ((m[i] * p[0] + m[4 + i] * p[1]) + m[8 + i] * p[2]) + m[12 + i] * 1.0f;
+}
+DSM_HD void xform_dir(const float *m, const float *v, float *o) {
+    for (int i = 0; i < 3; i++) o[i] = (m[i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2];
+}
+DSM_HD float depth_weight(float d) { // FF.cpp:99-102
+    double w = 1.0 / (double)d / (double)d;
+    return (float)(1.0 < w ? 1.0 : w);
+}
+DSM_HD float camera_focal(const Intrinsics &k) { // FF.cpp:250,350
+    return (float)((double)(fabsf(k.fx) + fabsf(k.fy)) / 2.0);
+}
+// int(x + 0.5) as x86-64 cvttsd2si does it (NaN / out of range -> INT_MIN), FF.cpp:235-236
+DSM_HD int round_to_pixel(float u) {
+    double ud = (double)u + 0.5;
+    return (ud >= -2147483648.0 && ud < 2147483648.0) ? (int)ud : (-2147483647 - 1);
+}
+
+// The plain-data views the fuse functions work on (layouts of elements.h:5-31).
+struct Surfel {
+    float px, py, pz, nx, ny, nz, size, color, weight;
+    int32_t update_times, last_update;
+};
+struct SeedView {  // the fields of Superpixel_seed that fusion reads
+    float size, nx, ny, nz, px, py, pz, view_cos, mean_depth, mean_intensity;
+};
+
+struct FuseConst {
+    Intrinsics k;
+    float far_d, near_d;
+    double baseline, disp_err, min_tol;
+    int w, h;
+};
+
+enum FuseOutcome { kFuseSkip = 0, kFuseDeleted = 1, kFuseFused = 2, kFuseNeedPixel = 3 };
+
+// Stage 1 of fuse_surfels_kernel (FF.cpp:205-238): pruning and projection.  Returns kFuseNeedPixel
+// with (ui,vi) and camera-frame position/normal when the surfel lands inside the image.
+DSM_HD FuseOutcome fuse_project(const FuseConst &c, int ref_idx, const float *inv, Surfel &e, int &ui, int &vi,
+                                float pc[3], float nc[3]) {
+    if (ref_idx - e.last_update > 5 && e.update_times < 5) {
+        e.update_times = 0;
+        return kFuseDeleted;
+    }
+    if (e.update_times == 0) return kFuseSkip;
+    float pw[3] = {e.px, e.py, e.pz}, nw[3] = {e.nx, e.ny, e.nz};
+    xform_point(inv, pw, pc);
+    if (pc[2] < c.near_d || pc[2] > c.far_d) return kFuseSkip;
+    xform_dir(inv, nw, nc);
+    float u = pc[0] * c.k.fx / pc[2] + c.k.cx, v = pc[1] * c.k.fy / pc[2] + c.k.cy; // FF.cpp:85-89
+    ui = round_to_pixel(u);
+    vi = round_to_pixel(v);
+    if (ui < 1 || ui > c.w - 2 || vi < 1 || vi > c.h - 2) return kFuseSkip;
+    return kFuseNeedPixel;
+}
+
+// Stage 2 (FF.cpp:239-311) given the depth at the projected pixel and the seed owning it.
+DSM_HD FuseOutcome fuse_update(const FuseConst &c, int ref_idx, const float *pose, Surfel &e, const float pc[3],
+                               const float nc[3], float pix_depth, const SeedView &sd) {
+    if ((double)pc[2] < (double)pix_depth - 1.0) {
+        e.update_times = 0;
+        return kFuseDeleted;
+    }
+    if (sd.nx == 0 && sd.ny == 0 && sd.nz == 0) return kFuseSkip;
+    if ((double)sd.view_cos < kAngleCos) return kFuseSkip;
+    float cam_f = camera_focal(c.k);
+    float tol = (float)((double)(pc[2] * pc[2]) / (c.baseline * (double)cam_f) * c.disp_err);
+    tol = (float)((double)tol < c.min_tol ? c.min_tol : (double)tol);
+    if (pc[2] < sd.mean_depth - tol) return kFuseSkip;
+    if (pc[2] > sd.mean_depth + tol) return kFuseSkip;
+    float ncos = nc[0] * sd.nx + nc[1] * sd.ny + nc[2] * sd.nz;
+    if ((double)ncos < kAngleCos) {
+        e.update_times = 0;
+        return kFuseDeleted;
+    }
+    float w0 = e.weight, w1 = depth_weight(sd.mean_depth), ws = w0 + w1;
+    float sc[3] = {sd.px, sd.py, sd.pz}, sw[3];
+    xform_point(pose, sc, sw);
+    float fpx = (e.px * w0 + w1 * sw[0]) / ws, fpy = (e.py * w0 + w1 * sw[1]) / ws, fpz = (e.pz * w0 + w1 * sw[2]) / ws;
+    float fn[3] = {nc[0] * w0 + w1 * sd.nx, nc[1] * w0 + w1 * sd.ny, nc[2] * w0 + w1 * sd.nz};
+    double len = (double)sqrtf(fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2]);
+    fn[0] = (float)((double)fn[0] / len);
+    fn[1] = (float)((double)fn[1] / len);
+    fn[2] = (float)((double)fn[2] / len);
+    float fw[3];
+    xform_dir(pose, fn, fw);
+    e.px = fpx; e.py = fpy; e.pz = fpz;
+    e.nx = fw[0]; e.ny = fw[1]; e.nz = fw[2];
+    e.weight = ws;
+    e.color = sd.mean_intensity;
+    float nsz = sd.size * fabsf(sd.mean_depth / (cam_f * sd.view_cos));
+    if (nsz < e.size) e.size = nsz;
+    e.last_update = ref_idx;
+    e.update_times += 1;
+    return kFuseFused;
+}
+
+// initialize_surfels, FF.cpp:315-361: does this seed create a surfel, and which one.
+DSM_HD bool seed_spawns(const SeedView &sd, bool fused) {
+    if (sd.mean_depth == 0) return false;
+    if (fused) return false;
+    if ((double)sd.view_cos < kAngleCos) return false;
+    if (sd.nx == 0 && sd.ny == 0 && sd.nz == 0) return false;
+    return true;
+}
+DSM_HD Surfel spawn_surfel(const Intrinsics &k, int ref_idx, const float *pose, const SeedView &sd) {
+    float pc[3] = {sd.px, sd.py, sd.pz}, nc[3] = {sd.nx, sd.ny, sd.nz}, pw[3], nw[3];
+    xform_point(pose, pc, pw);
+    xform_dir(pose, nc, nw);
+    float cam_f = camera_focal(k);
+    Surfel e;
+    e.px = pw[0]; e.py = pw[1]; e.pz = pw[2];
+    e.nx = nw[0]; e.ny = nw[1]; e.nz = nw[2];
+    e.size = sd.size * fabsf(sd.mean_depth / (cam_f * sd.view_cos));
+    e.color = sd.mean_intensity;
+    e.weight = depth_weight(sd.mean_depth);
+    e.update_times = 1;
+    e.last_update = ref_idx;
+    return e;
+}
+
+// worker k's [begin,end) over n items, FF.cpp:198-202 / 392-396 / 471-475
+DSM_HD int chunk_of(int n, int i) {
+    int step = n / kWorkers;
+    if (step == 0) return kWorkers - 1;
+    int k = i / step;
+    return k > kWorkers - 1 ? kWorkers - 1 : k;
+}
+
+} // namespace dsm

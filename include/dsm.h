@@ -1,0 +1,168 @@
+/* dsm.h -- C ABI of the MI355X-native surfel-fusion hot path.
+ *
+ * This is the boundary a maintainer of HKUST-Aerial-Robotics/DenseSurfelMapping binds
+ * instead of the in-process CPU engine.  Reference interfaces replaced (paths relative
+ * to the reference checkout):
+ *
+ *   dsm_create / dsm_destroy      <- FusionFunctions::initialize
+ *                                    surfel_fusion/src/fusion_functions.h:84-87, .cpp:7-28
+ *   dsm_fuse_initialize_map       <- FusionFunctions::fuse_initialize_map
+ *                                    surfel_fusion/src/fusion_functions.h:88-94, .cpp:30-83
+ *   dsm_fuse_map                  <- SurfelMap::fuse_map (engine call + hole refill /
+ *                                    swap-with-last compaction)
+ *                                    surfel_fusion/src/surfel_map.cpp:1060-1113
+ *   dsm_surfel / dsm_seed         <- SurfelElement / Superpixel_seed, bit-for-bit
+ *                                    surfel_fusion/src/elements.h:5-31
+ *
+ * Everything else (resident map, frame slots, replay queue, taps) is what an HBM-resident
+ * engine needs and the CPU reference has no counterpart for.
+ *
+ * Conventions: plain pointers and sizes, no exceptions; every call returns DSM_OK (0) or a
+ * negative dsm_status; dsm_last_error() gives the message.  A handle owns one HIP stream and
+ * all of its device buffers and is single-threaded-use (like a FusionFunctions instance,
+ * whose scratch buffers are members: fusion_functions.h:34-37); use one handle per
+ * concurrent subsequence.  There is no CPU fallback: dsm_create fails with
+ * DSM_E_NO_DEVICE when no gfx950 device is visible.
+ */
+#ifndef DSM_H
+#define DSM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSM_ABI_VERSION 1
+
+typedef enum {
+    DSM_OK = 0,
+    DSM_E_INVALID = -1,   /* bad argument (null pointer, dims, steps, slot index) */
+    DSM_E_NO_DEVICE = -2, /* no HIP device / not gfx950 */
+    DSM_E_HIP = -3,       /* a HIP runtime call failed; see dsm_last_error */
+    DSM_E_CAPACITY = -4,  /* surfel capacity exceeded */
+    DSM_E_STATE = -5      /* call made in the wrong state (e.g. nothing uploaded) */
+} dsm_status;
+
+/* elements.h:22-31 -- 44 bytes.  update_times == 0 marks a deleted slot. */
+typedef struct dsm_surfel {
+    float px, py, pz;
+    float nx, ny, nz;
+    float size;
+    float color;
+    float weight;
+    int32_t update_times;
+    int32_t last_update;
+} dsm_surfel;
+
+/* elements.h:5-20 -- 60 bytes (bool fused @48, bool stable @49, 2 pad bytes). */
+typedef struct dsm_seed {
+    float x, y;
+    float size;
+    float norm_x, norm_y, norm_z;
+    float posi_x, posi_y, posi_z;
+    float view_cos;
+    float mean_depth;
+    float mean_intensity;
+    uint8_t fused;
+    uint8_t stable;
+    uint8_t pad_[2];
+    float min_eigen_value, max_eigen_value;
+} dsm_seed;
+
+/* Constructor arguments of FusionFunctions::initialize plus the compile-time constant set of
+ * fusion_functions.h:7-21 made run-time (the RGB-D set of lines 17-21 is needed for
+ * 640x480 RGB-D input). */
+typedef struct dsm_config {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    float far_dist, near_dist;
+    double huber_range;       /* HUBER_RANGE        0.4  (rgbd 0.05) */
+    double baseline;          /* BASELINE           0.5  (rgbd 0.08) */
+    double disparity_error;   /* DISPARITY_ERROR    4.0  (rgbd 1.0)  */
+    double min_tolerate_diff; /* MIN_TOLERATE_DIFF  0.1  (rgbd 0.05) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t surfel_capacity;  /* max resident surfels; 0 = default (4 Mi) */
+    int32_t frame_slots;      /* resident frame slots in HBM; 0 = default (2) */
+    uint32_t flags;           /* DSM_FLAG_* */
+} dsm_config;
+
+#define DSM_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying a hipGraph */
+
+typedef struct dsm_handle dsm_handle;
+
+/* Fill cfg with the driving constant set (fusion_functions.h:13-16) or, if rgbd != 0, the
+ * RGB-D set (fusion_functions.h:17-21). */
+int dsm_config_init(dsm_config *cfg, int width, int height, float fx, float fy, float cx, float cy,
+                    float far_dist, float near_dist, int rgbd);
+
+int dsm_create(const dsm_config *cfg, dsm_handle **out);
+void dsm_destroy(dsm_handle *h);
+const char *dsm_last_error(const dsm_handle *h); /* h may be NULL: last dsm_create error */
+int dsm_abi_version(void);
+
+/* ---- drop-in calls (host buffers in, host buffers out; synchronous) -------------------- */
+
+/* FusionFunctions::fuse_initialize_map: image is 8-bit grey (img_step bytes per row), depth is
+ * float metres with 0 = invalid (depth_step bytes per row), pose16 is the cam->world matrix,
+ * column-major (Eigen::Matrix4f storage).  local[0..n_local) is updated in place; surfels
+ * created by this frame are written to new_out[0..*n_new) in seed order. */
+int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
+                            const float *depth, size_t depth_step, const float *pose16, dsm_surfel *local,
+                            int32_t n_local, dsm_surfel *new_out, int32_t new_cap, int32_t *n_new);
+
+/* SurfelMap::fuse_map: the call above followed by the reference's order-exact refill of deleted
+ * slots and swap-with-last compaction.  *n_local is updated; cap is the capacity of local[]. */
+int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
+                 const float *depth, size_t depth_step, const float *pose16, dsm_surfel *local,
+                 int32_t *n_local, int32_t cap, int32_t *n_new);
+
+/* ---- resident path: map and frames stay in HBM, calls are asynchronous on the handle's stream */
+
+int dsm_map_upload(dsm_handle *h, const dsm_surfel *surfels, int32_t n);
+int dsm_map_size(dsm_handle *h, int32_t *n);                       /* synchronises */
+int dsm_map_download(dsm_handle *h, dsm_surfel *out, int32_t cap, int32_t *n); /* synchronises */
+/* device-to-device copy of the resident map into caller-owned device memory (e.g. a torch
+ * tensor's data_ptr) for the multi-GPU merge; synchronises. */
+int dsm_map_copy_to_device(dsm_handle *h, void *dst_device, int32_t cap, int32_t *n);
+
+int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
+                     size_t depth_step);
+/* same, sources already in device memory */
+int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size_t img_step,
+                            const void *depth_dev, size_t depth_step);
+
+/* enqueue SurfelMap::fuse_map for the frame in `slot` against the resident map */
+int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, const float *pose16);
+/* enqueue n frames: frame i uses slots[i], ref_idx[i], poses16[16*i .. 16*i+16) */
+int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx,
+                       const float *poses16);
+int dsm_synchronize(dsm_handle *h);
+/* number of new surfels created by the last completed frame; synchronises */
+int dsm_last_new_count(dsm_handle *h, int32_t *n_new);
+/* the handle's hipStream_t, for event timing by the caller */
+int dsm_stream(dsm_handle *h, void **hip_stream);
+
+/* ---- parity taps (state after the last completed frame; synchronise) ------------------- */
+int dsm_get_labels(dsm_handle *h, int32_t *out /* height*width */);
+int dsm_get_seeds(dsm_handle *h, dsm_seed *out /* (width/8)*(height/8) */);
+int dsm_seed_count(const dsm_handle *h);
+
+/* ---- per-kernel timing (hip events on the handle's stream) ----------------------------- */
+#define DSM_MAX_STAGES 32
+typedef struct dsm_stage_times {
+    int32_t n_stages;
+    const char *name[DSM_MAX_STAGES];
+    double ms[DSM_MAX_STAGES];      /* accumulated kernel time per stage */
+    int64_t launches[DSM_MAX_STAGES];
+    int64_t frames;
+} dsm_stage_times;
+/* run the resident fuse for n frames eagerly with an event pair around every kernel and
+ * accumulate per-stage durations */
+int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx,
+                     const float *poses16, dsm_stage_times *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSM_H */

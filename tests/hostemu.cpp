@@ -1,0 +1,333 @@
+// TEST INFRASTRUCTURE (CPU, no GPU needed): a serial walk through the *GPU formulation* of the hot
+// path -- the same dsm_math.h the HIP kernels use, the same tmin / worklist fixed point, staged seed
+// commit, 20-accumulator Gauss-Newton and parallel-exact compaction as dsm_kernels.hip, with every
+// "thread" / "wave" executed one after the other.  tests/test_hostemu.py compares it with the oracle.
+// It validates the reformulations and the shared arithmetic before any GPU time is spent; it is
+// never loaded by the product package.
+//
+// Build: g++ -std=c++17 -O2 -ffp-contract=off -shared -fPIC tests/hostemu.cpp -o tests/_build/libhostemu.so
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../densesurfelmapping_amd/csrc/dsm_math.h"
+#include "../include/dsm.h"
+
+using namespace dsm;
+
+namespace {
+constexpr int kIntMax = 0x7fffffff;
+struct Core { float x, y, i, d; };
+
+struct Emu {
+    int w, h, gw, gh, S;
+    Intrinsics K;
+    float far_d, near_d;
+    double huber, baseline, disp_err, min_tol;
+    std::vector<int32_t> label, cand, tmin, stable_stage, worklist;
+    std::vector<Core> core, stage;
+    std::vector<double> inv_depth;
+    std::vector<dsm_seed> seeds;
+    int first_empty[kSweeps][kWorkers];
+    const uint8_t *img; size_t img_step;
+    const float *dep; size_t dep_step;
+    int order_salt = 0; // permutes "thread" execution order to exercise order independence
+
+    float I(int x, int y) const { return (float)img[(size_t)y * img_step + x]; }
+    float D(int x, int y) const { return *(const float *)((const char *)dep + (size_t)y * dep_step + (size_t)x * 4); }
+    int key(int x, int y) const { return y * w + x; }
+};
+
+void init_seeds(Emu &e) {
+    for (int s = 0; s < e.S; s++) {
+        int gx = s % e.gw, gy = s / e.gw;
+        int ix = gx * kCell + kCell / 2, iy = gy * kCell + kCell / 2;
+        float md = e.D(ix, iy);
+        if ((double)md < 0.01) {
+            int x0 = ix - kCell, y0 = iy - kCell, x1 = x0 + 2 * kCell, y1 = y0 + 2 * kCell;
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 > e.w - 1) x1 = e.w - 1;
+            if (y1 > e.h - 1) y1 = e.h - 1;
+            bool found = false;
+            for (int y = y0; y < y1 && !found; y++)
+                for (int x = x0; x < x1; x++)
+                    if ((double)e.D(x, y) > 0.01) { md = e.D(x, y); found = true; break; }
+        }
+        e.core[s] = {(float)ix, (float)iy, e.I(ix, iy), md};
+        e.inv_depth[s] = 1.0 / (double)md;
+        e.tmin[s] = -1;
+    }
+    for (int k = 0; k < kSweeps; k++)
+        for (int j = 0; j < kWorkers; j++) e.first_empty[k][j] = kIntMax;
+}
+
+void assign(Emu &e, bool first) {
+    e.worklist.clear();
+    const int n = e.w * e.h;
+    for (int q = 0; q < n; q++) {
+        // visit pixels in a scrambled order: the result must not depend on it
+        const int p = e.order_salt ? (int)(((int64_t)q * 7919 + e.order_salt) % n) : q;
+        const int x = p % e.w, y = p / e.w;
+        const int pick = pick_seed(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
+                                   [&](int gx, int gy, float &sx, float &sy, float &si, bool &hd, double &inv) {
+                                       const int s = gy * e.gw + gx;
+                                       sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i;
+                                       hd = e.core[s].d > 0; inv = e.inv_depth[s];
+                                   });
+        if (first) { e.label[p] = pick; continue; }
+        e.cand[p] = pick;
+        const int l = e.label[p];
+        if (e.tmin[l] == -1) {
+            if (e.tmin[pick] > p) e.tmin[pick] = p;
+        } else if (pick != l && e.tmin[pick] != -1) {
+            e.worklist.push_back(p);
+        }
+    }
+}
+
+void resolve(Emu &e) {
+    for (;;) {
+        bool changed = false;
+        for (size_t i = 0; i < e.worklist.size(); i++) {
+            const int p = e.worklist[e.order_salt ? e.worklist.size() - 1 - i : i];
+            const int l = e.label[p], pk = e.cand[p];
+            if (e.tmin[l] < p && e.tmin[pk] > p) { e.tmin[pk] = p; changed = true; }
+        }
+        if (!changed) break;
+    }
+}
+
+void apply(Emu &e) {
+    for (int p = 0; p < e.w * e.h; p++)
+        if (e.tmin[e.label[p]] < p) e.label[p] = e.cand[p];
+}
+
+void update_seeds(Emu &e, int sweep) {
+    float dl[256];
+    for (int s = 0; s < e.S; s++) {
+        if (e.tmin[s] == kIntMax) continue;
+        const int wx0 = (s % e.gw) * kCell + kCell / 2 - kCell, wy0 = (s / e.gw) * kCell + kCell / 2 - kCell;
+        int cnt = 0, sx = 0, sy = 0, si = 0, nd = 0;
+        for (int idx = 0; idx < 256; idx++) {
+            const int x = wx0 + (idx & 15), y = wy0 + (idx >> 4);
+            const bool in = x >= 0 && x < e.w - 1 && y >= 0 && y < e.h - 1;
+            if (!in || e.label[e.key(x, y)] != s) continue;
+            cnt++; sx += x; sy += y; si += (int)e.img[(size_t)y * e.img_step + x];
+            const float d = e.D(x, y);
+            if ((double)d > 0.1) dl[nd++] = d;
+        }
+        if (cnt == 0) {
+            int &fe = e.first_empty[sweep][chunk_of(e.S, s)];
+            if (s < fe) fe = s;
+            continue;
+        }
+        const float fn = (float)cnt;
+        const float mi = (float)si / fn, mx = (float)sx / fn, my = (float)sy / fn;
+        const Core old = e.core[s];
+        const float moved = fabsf(old.i - mi) + fabsf(old.x - mx) + fabsf(old.y - my);
+        float md = 0.0f;
+        if (nd > 0) {
+            float sum = 0.0f;
+            for (int i = 0; i < nd; i++) sum += dl[i];
+            md = huber_mean_depth(dl, nd, sum, e.huber);
+        }
+        e.stage[s] = {mx, my, mi, md};
+        e.stable_stage[s] = (double)moved < 0.2 ? 1 : 0;
+    }
+    for (int s = 0; s < e.S; s++) { // commit
+        if (e.tmin[s] == kIntMax) continue;
+        int t = -1;
+        if (s < e.first_empty[sweep][chunk_of(e.S, s)]) {
+            e.core[s] = e.stage[s];
+            e.inv_depth[s] = 1.0 / (double)e.stage[s].d;
+            if (e.stable_stage[s]) t = kIntMax;
+        }
+        e.tmin[s] = t;
+    }
+}
+
+void seed_planes(Emu &e) {
+    float ld[256], ln[768], lp[768];
+    int lx[256], ly[256];
+    for (int s = 0; s < e.S; s++) {
+        const Core core = e.core[s];
+        const int wx0 = (s % e.gw) * kCell + kCell / 2 - kCell, wy0 = (s / e.gw) * kCell + kCell / 2 - kCell;
+        int n = 0;
+        float far2 = 0.0f;
+        for (int idx = 0; idx < 256; idx++) {
+            const int x = wx0 + (idx & 15), y = wy0 + (idx >> 4);
+            if (!(x >= 0 && x < e.w && y >= 0 && y < e.h)) continue;
+            if (e.label[e.key(x, y)] != s) continue;
+            const float ex = (float)x - core.x, ey = (float)y - core.y;
+            const float d2 = ex * ex + ey * ey;
+            if (d2 > far2) far2 = d2;
+            const float d = e.D(x, y);
+            if ((double)d > 0.05) { ld[n] = d; lx[n] = x; ly[n] = y; n++; }
+        }
+        dsm_seed out;
+        memset(&out, 0, sizeof out);
+        out.x = core.x; out.y = core.y; out.mean_depth = core.d; out.mean_intensity = core.i;
+        out.stable = e.tmin[s] == kIntMax ? 1 : 0;
+        if (n >= 16) {
+            const float md = core.d;
+            int m = 0;
+            for (int i = 0; i < n; i++) {
+                const float r = md - ld[i];
+                if (!((double)r < e.huber && (double)r > -e.huber)) continue;
+                float nx = 0, ny = 0, nz = 0;
+                const int x = lx[i], y = ly[i];
+                if (x >= 1 && x <= e.w - 2 && y >= 1 && y <= e.h - 2)
+                    pixel_normal(e.K, x, y, ld[i], e.D(x + 1, y), e.D(x, y + 1), nx, ny, nz);
+                ln[m * 3] = nx; ln[m * 3 + 1] = ny; ln[m * 3 + 2] = nz;
+                back_project(e.K, (float)x, (float)y, ld[i], lp[m * 3], lp[m * 3 + 1], lp[m * 3 + 2]);
+                m++;
+            }
+            if (!((double)((float)m / (float)n) < 0.8)) {
+                float nx = 0, ny = 0, nz = 0, nb = 0, mx = 0, my = 0, mz = 0;
+                for (int i = 0; i < m; i++) {
+                    nx += ln[i * 3]; ny += ln[i * 3 + 1]; nz += ln[i * 3 + 2];
+                    mx += lp[i * 3]; my += lp[i * 3 + 1]; mz += lp[i * 3 + 2];
+                }
+                const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+                nx = nx / len; ny = ny / len; nz = nz / len;
+                mx /= (float)m; my /= (float)m; mz /= (float)m;
+                for (int i = 0; i < m; i++) { lp[i * 3] -= mx; lp[i * 3 + 1] -= my; lp[i * 3 + 2] -= mz; }
+                for (int it = 0; it < 5; it++) {
+                    double acc[20];
+                    for (int lane = 0; lane < 20; lane++) {
+                        GnTerm t;
+                        t.a = lane < 16 ? (lane & 3) : ((lane - 16) & 3);
+                        t.b = lane < 16 ? (lane >> 2) : -1;
+                        double a = 0.0;
+                        for (int i = 0; i < m; i++) {
+                            float p4[4] = {lp[i * 3], lp[i * 3 + 1], lp[i * 3 + 2], 1.0f};
+                            const float r = p4[0] * nx + p4[1] * ny + p4[2] * nz + nb;
+                            a = gn_term_add(a, t, p4, r, e.huber);
+                        }
+                        acc[lane] = a;
+                    }
+                    gn_step(acc, acc + 16, nx, ny, nz, nb);
+                }
+                plane_finish(nx, ny, nz, nb, mx, my, mz);
+                const SeedGeom g = seed_geometry(e.K, core.x, core.y, md, nx, ny, nz, nb);
+                out.norm_x = g.nx; out.norm_y = g.ny; out.norm_z = g.nz;
+                out.posi_x = g.px; out.posi_y = g.py; out.posi_z = g.pz;
+                out.mean_depth = g.mean_depth; out.view_cos = g.view_cos;
+                out.size = sqrtf(far2);
+            }
+        }
+        e.seeds[s] = out;
+    }
+}
+
+SeedView view_of(const dsm_seed &sp) {
+    SeedView sd;
+    sd.size = sp.size; sd.nx = sp.norm_x; sd.ny = sp.norm_y; sd.nz = sp.norm_z;
+    sd.px = sp.posi_x; sd.py = sp.posi_y; sd.pz = sp.posi_z;
+    sd.view_cos = sp.view_cos; sd.mean_depth = sp.mean_depth; sd.mean_intensity = sp.mean_intensity;
+    return sd;
+}
+
+void fuse(Emu &e, int ref_idx, const float *pose, const float *inv, dsm_surfel *local, int M) {
+    FuseConst fc;
+    fc.k = e.K; fc.far_d = e.far_d; fc.near_d = e.near_d;
+    fc.baseline = e.baseline; fc.disp_err = e.disp_err; fc.min_tol = e.min_tol; fc.w = e.w; fc.h = e.h;
+    for (int i = 0; i < M; i++) {
+        Surfel s;
+        memcpy(&s, &local[i], sizeof s);
+        int ui, vi;
+        float pc[3], nc[3];
+        FuseOutcome oc = fuse_project(fc, ref_idx, inv, s, ui, vi, pc, nc);
+        if (oc == kFuseNeedPixel) {
+            const int sidx = e.label[e.key(ui, vi)];
+            oc = fuse_update(fc, ref_idx, pose, s, pc, nc, e.D(ui, vi), view_of(e.seeds[sidx]));
+            if (oc == kFuseFused) e.seeds[sidx].fused = 1;
+        }
+        if (oc == kFuseDeleted) local[i].update_times = 0;
+        else if (oc == kFuseFused) memcpy(&local[i], &s, sizeof s);
+    }
+}
+
+int spawn(Emu &e, int ref_idx, const float *pose, dsm_surfel *fresh) {
+    int k = 0;
+    for (int s = 0; s < e.S; s++) {
+        const SeedView sd = view_of(e.seeds[s]);
+        if (!seed_spawns(sd, e.seeds[s].fused != 0)) continue;
+        const Surfel n = spawn_surfel(e.K, ref_idx, pose, sd);
+        memcpy(&fresh[k++], &n, sizeof n);
+    }
+    return k;
+}
+
+// parallel-exact form of SM.cpp:1087-1109, as k_hole_scan + k_compact do it
+int compact(dsm_surfel *local, int M, const dsm_surfel *fresh, int K) {
+    std::vector<int> holes, rank(M + 1, 0);
+    std::vector<char> is_hole(M, 0);
+    for (int i = 0; i < M; i++) {
+        rank[i] = (int)holes.size();
+        if (local[i].update_times == 0) { holes.push_back(i); is_hole[i] = 1; }
+    }
+    const int k = (int)holes.size();
+    if (K >= k) {
+        for (int j = 0; j < K; j++) local[j < k ? holes[k - 1 - j] : M + (j - k)] = fresh[j];
+        return M + K - k;
+    }
+    const int r = k - K, cut = M - r;
+    std::vector<dsm_surfel> snapshot(local, local + M); // reads must not see this pass's writes
+    for (int j = 0; j < K; j++) local[holes[k - 1 - j]] = fresh[j];
+    for (int i = 0; i < r; i++) {
+        const int tgt = holes[r - 1 - i];
+        if (tgt >= cut) continue;
+        int src = M - 1 - i;
+        while (is_hole[src] && rank[src] < r) src = M - 1 - (r - 1 - rank[src]);
+        local[tgt] = is_hole[src] ? fresh[k - 1 - rank[src]] : snapshot[src];
+    }
+    return cut;
+}
+} // namespace
+
+extern "C" {
+
+void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far_d, float near_d, int rgbd) {
+    Emu *e = new Emu();
+    e->w = w; e->h = h; e->gw = w / kCell; e->gh = h / kCell; e->S = e->gw * e->gh;
+    e->K = {fx, fy, cx, cy};
+    e->far_d = far_d; e->near_d = near_d;
+    if (rgbd) { e->huber = 0.05; e->baseline = 0.08; e->disp_err = 1.0; e->min_tol = 0.05; }
+    else { e->huber = 0.4; e->baseline = 0.5; e->disp_err = 4.0; e->min_tol = 0.1; }
+    e->label.assign((size_t)w * h, 0); e->cand.assign((size_t)w * h, 0);
+    e->tmin.assign(e->S, -1); e->stable_stage.assign(e->S, 0);
+    e->core.resize(e->S); e->stage.resize(e->S); e->inv_depth.resize(e->S); e->seeds.resize(e->S);
+    return e;
+}
+void emu_destroy(void *p) { delete (Emu *)p; }
+void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
+
+int emu_fuse_map(void *p, int ref_idx, const uint8_t *img, size_t img_step, const float *depth, size_t depth_step,
+                 const float *pose16, dsm_surfel *local, int *n_local, int cap, int *n_new) {
+    Emu &e = *(Emu *)p;
+    e.img = img; e.img_step = img_step; e.dep = depth; e.dep_step = depth_step;
+    init_seeds(e);
+    for (int sweep = 0; sweep < kSweeps; sweep++) {
+        assign(e, sweep == 0);
+        if (sweep) { resolve(e); apply(e); }
+        update_seeds(e, sweep);
+    }
+    seed_planes(e);
+    float inv[16];
+    inverse4<float>(pose16, inv);
+    fuse(e, ref_idx, pose16, inv, local, *n_local);
+    std::vector<dsm_surfel> fresh(e.S);
+    const int K = spawn(e, ref_idx, pose16, fresh.data());
+    if (*n_local + K > cap) return -1;
+    *n_local = compact(local, *n_local, fresh.data(), K);
+    *n_new = K;
+    return 0;
+}
+void emu_get_labels(void *p, int32_t *out) { Emu &e = *(Emu *)p; memcpy(out, e.label.data(), sizeof(int32_t) * e.label.size()); }
+void emu_get_seeds(void *p, dsm_seed *out) { Emu &e = *(Emu *)p; memcpy(out, e.seeds.data(), sizeof(dsm_seed) * e.seeds.size()); }
+int emu_compact(dsm_surfel *local, int n, const dsm_surfel *fresh, int k) { return compact(local, n, fresh, k); }
+
+} // extern "C"

@@ -1,0 +1,226 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): superpixel label image and surfel count bit-exact, float attributes
+within 1e-4 relative.  The HIP path reproduces the reference's operation order, so these tests hold it
+to the stricter bar first -- every byte equal, NaN == NaN -- and state the 1e-4 tolerance as the
+fallback contract in `fields_close`.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, fields_close, fields_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods(oracle_built):
+    from densesurfelmapping_amd import api, synth
+    from oracle import bindings
+    return api, synth, bindings
+
+
+def _compare_frame(tag, ff, orc, loc_g, loc_o):
+    lab_g, lab_o = ff.labels(), orc.labels()
+    n_bad = int((lab_g != lab_o).sum())
+    assert n_bad == 0, f"{tag}: {n_bad} label mismatches, first at {np.argwhere(lab_g != lab_o)[:5].tolist()}"
+    sg, so = ff.seeds(), orc.seeds()
+    bad = fields_equal(sg, so)
+    assert not bad, f"{tag}: seed table differs {bad}"
+    assert len(loc_g) == len(loc_o), f"{tag}: surfel count {len(loc_g)} vs {len(loc_o)}"
+    bad = fields_equal(loc_g, loc_o)
+    assert not bad, f"{tag}: surfels differ {bad}"
+    fields_close(loc_g, loc_o, rtol=1e-4)
+
+
+@pytest.mark.parametrize("flags", [1, 0], ids=["eager", "graph"])
+def test_dropin_fuse_map_tiny_sequence(mods, flags):
+    """SurfelMap::fuse_map drop-in, host buffers in/out, 60 frames (prune + compaction reached)."""
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene()
+    ff = api.FusionFunctions.from_camera(cam, flags=flags, surfel_capacity=65536)
+    orc = ob.PortOracle(cam)
+    lg = np.zeros(0, api.SURFEL_DTYPE)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, 60):
+        lg, kg = ff.fuse_map(ref, img, dep, pose, lg)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert kg == ko, f"frame {t}: new surfel count {kg} vs {ko}"
+        _compare_frame(f"frame {t}", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+
+
+def test_dropin_fuse_initialize_map(mods):
+    """FusionFunctions::fuse_initialize_map drop-in: local updated in place, new surfels separate."""
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene(seed=7)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    orc = ob.PortOracle(cam)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, 12):
+        g_local, g_new = ff.fuse_initialize_map(ref, img, dep, pose, lo)
+        o_local, o_new = orc.fuse_initialize_map(ref, img, dep, pose, lo)
+        assert not fields_equal(g_local, o_local.astype(api.SURFEL_DTYPE)), f"frame {t} local"
+        assert not fields_equal(g_new, o_new.astype(api.SURFEL_DTYPE)), f"frame {t} new"
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+
+
+def test_resident_replay_kitti(mods):
+    """BASELINE config 2 shape: 1226x370, map and frames resident in HBM, one graph replay per frame."""
+    api, synth, ob = mods
+    cam, scene = synth.KITTI_1226, synth.Scene()
+    n = 16
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 20)
+    orc = ob.PortOracle(cam)
+    frames = list(synth.sequence(cam, scene, n))
+    for t, img, dep, pose, ref in frames:
+        ff.frame_upload(t, img, dep)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in frames:
+        ff.fuse_frame_resident(t, ref, pose)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert ff.last_new_count() == ko
+        _compare_frame(f"kitti frame {t}", ff, orc, ff.map_download(), lo.astype(api.SURFEL_DTYPE))
+
+
+def test_batched_replay_matches_stepwise(mods):
+    """dsm_replay_enqueue of a whole subsequence (no host sync in between) == frame-by-frame."""
+    api, synth, ob = mods
+    cam, scene = synth.VGA_DRIVE, synth.Scene(seed=99)
+    n = 24
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 20)
+    orc = ob.PortOracle(cam)
+    frames = list(synth.sequence(cam, scene, n))
+    for t, img, dep, pose, ref in frames:
+        ff.frame_upload(t, img, dep)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    slots, refs, poses = api.FusionFunctions.pack_replay([f[0] for f in frames], [f[4] for f in frames],
+                                                         np.stack([f[3] for f in frames]))
+    ff.replay_enqueue(slots, refs, poses)
+    ff.synchronize()
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in frames:
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+    _compare_frame("after 24 frames", ff, orc, ff.map_download(), lo.astype(api.SURFEL_DTYPE))
+
+
+def test_rgbd_constant_set(mods):
+    """BASELINE config 4 shape: 640x480 with the RGB-D constants of fusion_functions.h:17-21."""
+    api, synth, ob = mods
+    cam, scene = synth.VGA_RGBD, synth.Scene(scale=0.12, step=0.05, seed=5)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
+    orc = ob.PortOracle(cam)
+    lg = np.zeros(0, api.SURFEL_DTYPE)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, 8):
+        lg, kg = ff.fuse_map(ref, img, dep, pose, lg)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert kg == ko
+        _compare_frame(f"rgbd frame {t}", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+
+
+def test_edge_inputs(mods):
+    """Empty depth (no surfels), all-holes rows, constant image: same answers as the oracle."""
+    api, synth, ob = mods
+    cam = synth.TINY
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    orc = ob.PortOracle(cam)
+    rng = np.random.default_rng(3)
+    pose = np.eye(4, dtype=np.float32)
+    cases = {
+        "zero depth": (np.full((cam.height, cam.width), 100, np.uint8), np.zeros((cam.height, cam.width), np.float32)),
+        "flat wall": (np.full((cam.height, cam.width), 128, np.uint8), np.full((cam.height, cam.width), 4.0, np.float32)),
+        "noise": (rng.integers(0, 256, (cam.height, cam.width)).astype(np.uint8),
+                  rng.uniform(0.0, 8.0, (cam.height, cam.width)).astype(np.float32)),
+    }
+    half = cases["flat wall"][1].copy()
+    half[::2] = 0.0
+    cases["striped holes"] = (cases["noise"][0], half)
+    for name, (img, dep) in cases.items():
+        lg, kg = ff.fuse_map(0, img, dep, pose, np.zeros(0, api.SURFEL_DTYPE))
+        lo, ko = orc.fuse_map(0, img, dep, pose, np.zeros(0, ob.SURFEL_DTYPE))
+        assert kg == ko, name
+        _compare_frame(name, ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+        # second pass over the map just created (fusion branch)
+        lg, kg = ff.fuse_map(1, img, dep, pose, lg)
+        lo, ko = orc.fuse_map(1, img, dep, pose, lo)
+        _compare_frame(name + " (2nd)", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+
+
+def test_compaction_with_many_holes(mods):
+    """Maps whose surfels are mostly stale (pruned this frame): the K < k branch with tail holes."""
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene()
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    orc = ob.PortOracle(cam)
+    rng = np.random.default_rng(11)
+    seq = list(synth.sequence(cam, scene, 6))
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in seq[:5]:
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+    for trial in range(8):
+        m = lo.copy()
+        stale = rng.random(len(m)) < rng.uniform(0.1, 0.9)
+        m["last_update"][stale] = -100  # ref - last_update > 5
+        m["update_times"][stale] = rng.integers(1, 5, int(stale.sum()))
+        t, img, dep, pose, ref = seq[5]
+        g, kg = ff.fuse_map(ref, img, dep, pose, m.astype(api.SURFEL_DTYPE))
+        o, ko = orc.fuse_map(ref, img, dep, pose, m)
+        assert kg == ko and len(g) == len(o), f"trial {trial}"
+        assert not fields_equal(g, o.astype(api.SURFEL_DTYPE)), f"trial {trial}"
+        assert (g["update_times"] != 0).all()
+
+
+def test_full_size_properties(mods):
+    """Size-independent properties at BASELINE's full sizes (no oracle): determinism, graph == eager,
+    labels in range and local, no deleted slot survives compaction, count identity."""
+    api, synth, ob = mods
+    for cam in (synth.KITTI_1226, synth.FULLHD):
+        scene = synth.Scene(seed=21)
+        n = 6
+        frames = list(synth.sequence(cam, scene, n))
+        results = []
+        for flags in (0, 0, 1):
+            ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 20, flags=flags)
+            for t, img, dep, pose, ref in frames:
+                ff.frame_upload(t, img, dep)
+            ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+            sizes = []
+            for t, img, dep, pose, ref in frames:
+                before = ff.map_size()
+                ff.fuse_frame_resident(t, ref, pose)
+                after, k = ff.map_size(), ff.last_new_count()
+                sizes.append((before, k, after))
+                assert after <= before + k
+            m = ff.map_download()
+            lab = ff.labels()
+            results.append((m.tobytes(), lab.tobytes(), sizes))
+            assert (m["update_times"] != 0).all()
+            gw, gh = cam.width // 8, cam.height // 8
+            assert lab.min() >= 0 and lab.max() < gw * gh
+            ys, xs = np.mgrid[0:cam.height, 0:cam.width]
+            assert (np.abs((lab % gw) * 8 + 4 - xs) < 8).all() and (np.abs((lab // gw) * 8 + 4 - ys) < 8).all()
+            ff.close()
+        assert results[0] == results[1], "two identical runs differ"
+        assert results[0] == results[2], "graph replay and eager launch differ"
+
+
+def test_golden_fixture(mods):
+    """Committed vectors generated from the reference's own translation unit (tests/golden/make_golden.py)."""
+    api, synth, ob = mods
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    for case in meta["cases"]:
+        cam = getattr(synth, case["camera"])
+        scene = synth.Scene(**case["scene"])
+        ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
+        lg = np.zeros(0, api.SURFEL_DTYPE)
+        for (t, img, dep, pose, ref), want in zip(synth.sequence(cam, scene, case["frames"]), case["per_frame"]):
+            lg, k = ff.fuse_map(ref, img, dep, pose, lg)
+            assert k == want["n_new"] and len(lg) == want["n_local"], f"{case['name']} frame {t}"
+            assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == want["labels_sha256"], f"{case['name']} frame {t}"
+        ref_map = np.load(os.path.join(ROOT, "tests", "golden", case["final_map"]))
+        assert not fields_equal(lg, ref_map.astype(api.SURFEL_DTYPE)), case["name"]
