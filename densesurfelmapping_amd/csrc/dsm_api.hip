@@ -140,7 +140,7 @@ int check_status(dsm_handle *h) {
     // caller has synchronised and copied status into h_scalars[2]
     const int st = h->h_scalars[2];
     if (st & kStatusCapacity) return fail(h, DSM_E_CAPACITY, "resident surfel capacity %d exceeded", h->hc.cap);
-    if (st & kStatusBadPick) return fail(h, DSM_E_INVALID, "a pixel had no candidate superpixel (unsupported image size)");
+    if (st & kStatusBadPick) return fail(h, DSM_E_INVALID, "a pixel had no candidate superpixel below the reference's 1e6 cost sentinel (depth outside the sensor range?); the reference indexes seeds[-1] here");
     return DSM_OK;
 }
 

@@ -134,8 +134,11 @@ def test_edge_inputs(mods):
     cases = {
         "zero depth": (np.full((cam.height, cam.width), 100, np.uint8), np.zeros((cam.height, cam.width), np.float32)),
         "flat wall": (np.full((cam.height, cam.width), 128, np.uint8), np.full((cam.height, cam.width), 4.0, np.float32)),
+        # depth stays in the sensor's range: values in (0.01, ~0.05) m make every candidate cost exceed
+        # the reference's 1e6 sentinel, after which it indexes superpixel_seeds[-1] (FF.cpp:442-451)
         "noise": (rng.integers(0, 256, (cam.height, cam.width)).astype(np.uint8),
-                  rng.uniform(0.0, 8.0, (cam.height, cam.width)).astype(np.float32)),
+                  np.where(rng.random((cam.height, cam.width)) < 0.15, 0.0,
+                           rng.uniform(0.4, 8.0, (cam.height, cam.width))).astype(np.float32)),
     }
     half = cases["flat wall"][1].copy()
     half[::2] = 0.0
@@ -173,6 +176,20 @@ def test_compaction_with_many_holes(mods):
         assert kg == ko and len(g) == len(o), f"trial {trial}"
         assert not fields_equal(g, o.astype(api.SURFEL_DTYPE)), f"trial {trial}"
         assert (g["update_times"] != 0).all()
+
+
+def test_out_of_domain_depth_is_reported(mods):
+    """Depths of a few centimetres push every SLIC cost past the reference's 1e6 sentinel; the
+    reference then reads superpixel_seeds[-1].  The HIP path reports DSM_E_INVALID instead."""
+    api, synth, ob = mods
+    cam = synth.TINY
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    img = np.full((cam.height, cam.width), 90, np.uint8)
+    dep = np.full((cam.height, cam.width), 5.0, np.float32)
+    dep[::3, ::5] = 0.011
+    with pytest.raises(api.DsmError) as ei:
+        ff.fuse_map(0, img, dep, np.eye(4, dtype=np.float32), np.zeros(0, api.SURFEL_DTYPE))
+    assert ei.value.code == -1
 
 
 def test_full_size_properties(mods):
