@@ -139,6 +139,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
 int check_status(dsm_handle *h) {
     // caller has synchronised and copied status into h_scalars[2]
     const int st = h->h_scalars[2];
+    if (st) (void)hipMemsetAsync(h->hc.status, 0, 4, h->stream); // report once, then start clean
     if (st & kStatusCapacity) return fail(h, DSM_E_CAPACITY, "resident surfel capacity %d exceeded", h->hc.cap);
     if (st & kStatusBadPick) return fail(h, DSM_E_INVALID, "a pixel had no candidate superpixel below the reference's 1e6 cost sentinel (depth outside the sensor range?); the reference indexes seeds[-1] here");
     return DSM_OK;
@@ -214,6 +215,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     // indexes superpixel_seeds[-1] (FF.cpp:442-451).  Refuse instead of inventing behaviour.
     if (w % kCell > kCell / 2 || hh % kCell > kCell / 2)
         return fail(nullptr, DSM_E_INVALID, "image size %dx%d: (size mod 8) > 4 is undefined in the reference", w, hh);
+    if ((w / kCell) * (hh / kCell) > 64 * 1024) return fail(nullptr, DSM_E_INVALID, "more than 65536 superpixels");
     if (!(cfg->fx != 0) || !(cfg->fy != 0)) return fail(nullptr, DSM_E_INVALID, "zero focal length");
 
     int n_dev = 0;

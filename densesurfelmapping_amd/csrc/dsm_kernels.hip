@@ -46,6 +46,24 @@ __device__ __forceinline__ int load_coherent(const int32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Ordered fp32 sum a = (((0 + l[0]) + l[1]) + ...) of an LDS list: the loads are block-fetched 8 at a
+// time (two ds_read_b128) so that only the adds are loop-carried.  l is 16-byte aligned and padded
+// with +0.0f up to a multiple of 8 (a running sum that starts at +0.0f can never be -0.0f, so adding
+// +0.0f is the identity, bit for bit).
+__device__ __forceinline__ float ordered_sum(const float *l, int n) {
+    float a = 0.0f;
+    for (int i = 0; i < n; i += 8) {
+        const float4 u = *reinterpret_cast<const float4 *>(l + i), v = *reinterpret_cast<const float4 *>(l + i + 4);
+        a += u.x; a += u.y; a += u.z; a += u.w;
+        a += v.x; a += v.y; a += v.z; a += v.w;
+    }
+    return a;
+}
+// zero the padding slots [n, round_up(n, 8)) of a column
+__device__ __forceinline__ void pad_column(float *l, int n, int lane) {
+    if (lane < 8 && n + lane < ((n + 7) & ~7)) l[n + lane] = 0.0f;
+}
+
 __device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) {
     return c->params[(unsigned)c->cursor[0] % (unsigned)c->n_params];
 }
@@ -61,31 +79,56 @@ __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx *__restrict_
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
     if (s == 0) c->work_count[0] = 0;
-    if (s >= c->n_seed) return;
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
-    const int gx = s % c->gw, gy = s / c->gw;
-    int ix = gx * kCell + kCell / 2, iy = gy * kCell + kCell / 2;
-    if (ix > w - 1) ix = w - 1;
-    if (iy > h - 1) iy = h - 1;
-    float md = dep[iy * pitch + ix];
-    if ((double)md < 0.01) { // FF.cpp:600-626: first depth > 0.01 in the clipped window, row-major
-        int x0 = gx * kCell + kCell / 2 - kCell, y0 = gy * kCell + kCell / 2 - kCell;
-        int x1 = x0 + 2 * kCell, y1 = y0 + 2 * kCell;
-        if (x0 < 0) x0 = 0;
-        if (y0 < 0) y0 = 0;
-        if (x1 > w - 1) x1 = w - 1;
-        if (y1 > h - 1) y1 = h - 1;
-        bool found = false;
-        for (int y = y0; y < y1 && !found; y++)
-            for (int x = x0; x < x1; x++) {
-                float d = dep[y * pitch + x];
-                if ((double)d > 0.01) { md = d; found = true; break; }
-            }
+    const bool live = s < c->n_seed;
+    int gx = 0, gy = 0, ix = 0, iy = 0;
+    float md = 1.0f, mi = 0.0f;
+    if (live) {
+        gx = s % c->gw; gy = s / c->gw;
+        ix = gx * kCell + kCell / 2; iy = gy * kCell + kCell / 2;
+        if (ix > w - 1) ix = w - 1;
+        if (iy > h - 1) iy = h - 1;
+        md = dep[iy * pitch + ix];
+        mi = (float)img[iy * pitch + ix];
     }
-    c->core[s] = make_float4((float)ix, (float)iy, (float)img[iy * pitch + ix], md);
+    // FF.cpp:600-626: a seed whose centre has no depth takes the first depth > 0.01 of its clipped
+    // window in row-major order.  Whole image regions (sky) need it at once, so every lane scans its
+    // own window, four rows (16 independent 16-byte loads) per round trip.
+    if (live && (double)md < 0.01) {
+        const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+        const int x_lo = wx0 < 0 ? 0 : wx0, x_hi = wx0 + 2 * kCell > w - 1 ? w - 1 : wx0 + 2 * kCell;
+        const int y_lo = wy0 < 0 ? 0 : wy0, y_hi = wy0 + 2 * kCell > h - 1 ? h - 1 : wy0 + 2 * kCell;
+        bool found = false;
+        for (int yb = y_lo; yb < y_hi && !found; yb += 4) {
+            float4 v[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int y = yb + r < y_hi ? yb + r : y_hi - 1, x = wx0 + 4 * q;
+                    v[r][q] = x >= 0 ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float e[4] = {v[r][q].x, v[r][q].y, v[r][q].z, v[r][q].w};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int x = wx0 + 4 * q + t;
+                        if (!found && yb + r < y_hi && x >= x_lo && x < x_hi && (double)e[t] > 0.01) {
+                            md = e[t];
+                            found = true;
+                        }
+                    }
+                }
+        }
+    }
+    if (!live) return;
+    c->core[s] = make_float4((float)ix, (float)iy, mi, md);
     c->inv_depth[s] = 1.0 / (double)md;
     c->tmin[s] = -1; // fused = stable = false
 }
@@ -186,6 +229,36 @@ __global__ __launch_bounds__(256) void k_apply(const DeviceCtx *__restrict__ c) 
     if (c->tmin[l] < p) c->label[p] = c->cand[p];
 }
 
+// Ordered sum of one Huber-Newton pass (FF.cpp:536-549): element i adds lt[i] = 2*r if its residual is
+// in the Huber core, else a = (float)((double)a +- hr).  tail/pos are wave-uniform bit masks per
+// 64 elements; blocks without outliers take the plain path.
+__device__ __forceinline__ float huber_ordered_sum(const float *lt, int nd, const unsigned long long tail[4],
+                                                   const unsigned long long pos[4], double hr) {
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int lim = nd - k * 64 < 64 ? nd - k * 64 : 64;
+        if (lim <= 0) break;
+        for (int j = 0; j < lim; j += 8) {
+            const float4 u = *reinterpret_cast<const float4 *>(lt + k * 64 + j);
+            const float4 v = *reinterpret_cast<const float4 *>(lt + k * 64 + j + 4);
+            const unsigned t8 = (unsigned)(tail[k] >> j) & 0xffu, p8 = (unsigned)(pos[k] >> j) & 0xffu;
+            if (t8 == 0) {
+                a += u.x; a += u.y; a += u.z; a += u.w;
+                a += v.x; a += v.y; a += v.z; a += v.w;
+            } else {
+                const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if ((t8 >> q) & 1u) a = (float)((double)a + (((p8 >> q) & 1u) ? hr : -1 * hr));
+                    else a += e[q];
+                }
+            }
+        }
+    }
+    return a;
+}
+
 // ------------------------------------------------------------------------------ update seeds
 // One wave per seed.  Lanes cover the 16x16 window (4 pixels each, row-major across k*64+lane).
 // Counts and coordinate/intensity sums are integers (exact in the reference's fp32 accumulators,
@@ -194,7 +267,8 @@ __global__ __launch_bounds__(256) void k_apply(const DeviceCtx *__restrict__ c) 
 constexpr int kWin = 2 * kCell; // 16
 
 __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restrict__ c, int sweep) {
-    __shared__ float s_depth[4][kWin * kWin];
+    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
+    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = blockIdx.x * 4 + wv;
     if (s >= c->n_seed) return;
@@ -204,7 +278,7 @@ __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restric
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
     const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
-    float *dl = s_depth[wv];
+    float *dl = s_depth[wv], *lt = s_term[wv];
     int cnt = 0, sx = 0, sy = 0, si = 0, nd = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -238,9 +312,38 @@ __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restric
     const int stable = (double)moved < 0.2 ? 1 : 0;
     float md = 0.0f;
     if (nd > 0) {
-        float sum = 0.0f;
-        for (int i = 0; i < nd; i++) sum += dl[i];
-        md = huber_mean_depth(dl, nd, sum, c->huber);
+        // FF.cpp:530-556.  The loop-carried part of a Huber-Newton pass is only the ordered fp32 sum of
+        // the per-element terms; residuals and their classification are computed lane-parallel.
+        const double hr = c->huber;
+        pad_column(dl, nd, lane);
+        pad_column(lt, nd, lane); // pad slots stay +0.0f: the passes below only write valid slots
+        wave_lds_sync();
+        md = ordered_sum(dl, nd) / (float)nd;
+        float dk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dk[k] = (k * 64 + lane < nd) ? dl[k * 64 + lane] : 0.0f;
+        for (int it = 0; it < 5; it++) {
+            unsigned long long tail[4], pos[4];
+            int n_core = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int idx = k * 64 + lane;
+                const bool valid = idx < nd;
+                const float r = md - dk[k];
+                const bool core = valid && (double)r < hr && (double)r > -hr;
+                if (valid) lt[idx] = 2 * r;
+                tail[k] = __ballot(valid && !core);
+                pos[k] = __ballot(valid && !core && r > 0);
+                n_core += __popcll(__ballot(core));
+            }
+            wave_lds_sync();
+            const float a = huber_ordered_sum(lt, nd, tail, pos, hr);
+            const float b = (float)(2 * n_core); // the reference adds 2.0f per core element: exact
+            const float delta = (float)((double)(-a) / ((double)b + 10.0));
+            md = md + delta;
+            wave_lds_sync();
+            if ((double)delta < 0.01 && (double)delta > -0.01) break;
+        }
     }
     if (lane == 0) {
         c->core_stage[s] = make_float4(mx, my, mi, md);
@@ -269,13 +372,53 @@ __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx *__restric
 // depth inliers, average their forward-difference normals, refine a plane by 5 Huber-weighted
 // Gauss-Newton steps and derive position / view angle / size.  Back-projections and pixel normals
 // are recomputed from the depth plane (the reference's 36 B/pixel space_map and norm_map never
-// exist in memory).  All order-sensitive sums run in the reference's order; the 20 double
-// accumulators of a Gauss-Newton step are independent, so 20 lanes each carry one.
+// exist in memory).  Every order-sensitive sum runs in the reference's order, but only the adds are
+// serial: operands are produced lane-parallel, parked in LDS as structure-of-arrays columns and
+// block-fetched.  The 16 Hessian + 4 Jacobian double accumulators of a Gauss-Newton step are
+// independent ordered sums, so 20 lanes each carry one:
+//     H(a,b) += (double)((2*p_a)*p_b),  J(a) += (double)((2*r)*p_a)   (p_3 = 1; core residuals)
+//     J(a)   += +-hr*(double)p_a                                      (Huber tails)
+// i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}.
+constexpr int kCols = 10; // LDS columns per wave: p0 p1 p2 r ones | n0 n1 n2 | depth | packed xy
+
+// Ordered double sum of one accumulator over the (padded) inlier list.  Blocks of 8 whose residuals are
+// all in the Huber core take the plain path; otherwise the class of each element comes from the
+// wave-uniform masks (noncore / upper / lower), and only Jacobian lanes add the tail term.
+__device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *yc, int m, const unsigned long long noncore[4],
+                                                 const unsigned long long upper[4], const unsigned long long lower[4],
+                                                 bool is_j, double hr) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int lim = m - k * 64 < 64 ? m - k * 64 : 64;
+        if (lim <= 0) break;
+        for (int j = 0; j < lim; j += 8) {
+            const int b = k * 64 + j;
+            const float4 xa = *reinterpret_cast<const float4 *>(xc + b), xb = *reinterpret_cast<const float4 *>(xc + b + 4);
+            const float4 ya = *reinterpret_cast<const float4 *>(yc + b), yb = *reinterpret_cast<const float4 *>(yc + b + 4);
+            const unsigned n8 = (unsigned)(noncore[k] >> j) & 0xffu;
+            if (n8 == 0) {
+                acc += (double)(2 * xa.x * ya.x); acc += (double)(2 * xa.y * ya.y);
+                acc += (double)(2 * xa.z * ya.z); acc += (double)(2 * xa.w * ya.w);
+                acc += (double)(2 * xb.x * yb.x); acc += (double)(2 * xb.y * yb.y);
+                acc += (double)(2 * xb.z * yb.z); acc += (double)(2 * xb.w * yb.w);
+            } else {
+                const unsigned u8 = (unsigned)(upper[k] >> j) & 0xffu, l8 = (unsigned)(lower[k] >> j) & 0xffu;
+                const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int cls = !((n8 >> q) & 1u) ? 0 : ((u8 >> q) & 1u) ? 1 : ((l8 >> q) & 1u) ? 2 : 3;
+                    acc += gn_term(is_j, xs[q], ys[q], cls, hr);
+                }
+            }
+        }
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict__ c) {
-    __shared__ float s_d[4][kWin * kWin];
-    __shared__ int s_xy[4][kWin * kWin];
-    __shared__ float s_n[4][kWin * kWin * 3];
-    __shared__ float s_p[4][kWin * kWin * 3];
+    __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = blockIdx.x * 4 + wv;
     if (s >= c->n_seed) return;
@@ -285,9 +428,11 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
     const Intrinsics K = c->k;
     const double hr = c->huber;
     const float4 core = c->core[s];
+    const int is_stable = c->tmin[s] == kIntMax ? 1 : 0;
     const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
-    float *ld = s_d[wv], *ln = s_n[wv], *lp = s_p[wv];
-    int *lxy = s_xy[wv];
+    float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2], *R = s_col[wv][3];
+    float *ONE = s_col[wv][4], *N0 = s_col[wv][5], *N1 = s_col[wv][6], *N2 = s_col[wv][7], *ld = s_col[wv][8];
+    int *lxy = reinterpret_cast<int *>(s_col[wv][9]);
 
     // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
     int n = 0;
@@ -326,11 +471,10 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
     out.mean_depth = core.w;
     out.mean_intensity = core.z;
     out.fused = 0;
-    out.stable = c->tmin[s] == kIntMax ? 1 : 0;
+    out.stable = (uint8_t)is_stable;
     out.pad_[0] = out.pad_[1] = 0;
     out.min_eigen_value = out.max_eigen_value = 0;
 
-    bool fitted = false;
     if (n >= 16) { // FF.cpp:841
         // ---- depth inliers: their pixel normals and back-projected points, in order (FF.cpp:846-861)
         const float md = core.w;
@@ -353,41 +497,58 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
                 float nx = 0.0f, ny = 0.0f, nz = 0.0f;
                 if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) // FF.cpp:670-677
                     pixel_normal(K, x, y, d, dep[y * pitch + x + 1], dep[(y + 1) * pitch + x], nx, ny, nz);
-                ln[pos * 3] = nx; ln[pos * 3 + 1] = ny; ln[pos * 3 + 2] = nz;
+                N0[pos] = nx; N1[pos] = ny; N2[pos] = nz;
                 float px, py, pz;
                 back_project(K, (float)x, (float)y, d, px, py, pz);
-                lp[pos * 3] = px; lp[pos * 3 + 1] = py; lp[pos * 3 + 2] = pz;
+                P0[pos] = px; P1[pos] = py; P2[pos] = pz; ONE[pos] = 1.0f;
             }
             m_in += __popcll(m);
         }
+        // pad every column the ordered sums stream to a multiple of 8 with +0.0f (see ordered_sum)
+        pad_column(P0, m_in, lane); pad_column(P1, m_in, lane); pad_column(P2, m_in, lane);
+        pad_column(R, m_in, lane); pad_column(ONE, m_in, lane);
+        pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
         wave_lds_sync();
         if (!((double)((float)m_in / (float)n) < 0.8)) { // FF.cpp:862
-            float nx = 0, ny = 0, nz = 0, nb = 0;
-            float mx = 0, my = 0, mz = 0;
-            for (int i = 0; i < m_in; i++) { // sequential fp32 sums, FF.cpp:852-857 and 111-116
-                nx += ln[i * 3]; ny += ln[i * 3 + 1]; nz += ln[i * 3 + 2];
-                mx += lp[i * 3]; my += lp[i * 3 + 1]; mz += lp[i * 3 + 2];
-            }
+            // sequential fp32 sums, FF.cpp:852-857 and 111-116
+            float nx = ordered_sum(N0, m_in), ny = ordered_sum(N1, m_in), nz = ordered_sum(N2, m_in), nb = 0;
+            float mx = ordered_sum(P0, m_in), my = ordered_sum(P1, m_in), mz = ordered_sum(P2, m_in);
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
             nx = nx / len; ny = ny / len; nz = nz / len;
             mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
             wave_lds_sync();
-            for (int i = lane; i < m_in; i += 64) { // centre the points, FF.cpp:121-126
-                lp[i * 3] -= mx; lp[i * 3 + 1] -= my; lp[i * 3 + 2] -= mz;
-            }
-            wave_lds_sync();
-            // lanes 0..15: Hessian entry (a = lane & 3, b = lane >> 2); lanes 16..19: Jacobian entry
-            GnTerm term;
-            term.a = lane < 16 ? (lane & 3) : ((lane - 16) & 3);
-            term.b = lane < 16 ? (lane >> 2) : -1;
-            const bool carries = lane < 20;
-            for (int it = 0; it < 5; it++) {
-                double acc = 0.0;
-                for (int i = 0; i < m_in; i++) {
-                    float p4[4] = {lp[i * 3], lp[i * 3 + 1], lp[i * 3 + 2], 1.0f};
-                    const float r = p4[0] * nx + p4[1] * ny + p4[2] * nz + nb;
-                    if (carries) acc = gn_term_add(acc, term, p4, r, hr);
+            float q0[4], q1[4], q2[4]; // this lane's (centred) points, FF.cpp:121-126
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = k * 64 + lane;
+                q0[k] = q1[k] = q2[k] = 0.0f;
+                if (i < m_in) {
+                    q0[k] = P0[i] - mx; q1[k] = P1[i] - my; q2[k] = P2[i] - mz;
+                    P0[i] = q0[k]; P1[i] = q1[k]; P2[i] = q2[k];
                 }
+            }
+            // operand columns of this lane's accumulator
+            const bool is_j = lane >= 16;
+            const int ta = lane < 16 ? (lane & 3) : ((lane - 16) & 3), tb = (lane >> 2) & 3;
+            const int xs = is_j ? 4 : ta, ys = is_j ? ta : tb; // 0..2 = p, 3 = ones, 4 = r
+            const float *xc = xs == 0 ? P0 : xs == 1 ? P1 : xs == 2 ? P2 : xs == 3 ? ONE : R;
+            const float *yc = ys == 0 ? P0 : ys == 1 ? P1 : ys == 2 ? P2 : ONE;
+            for (int it = 0; it < 5; it++) {
+                unsigned long long noncore[4], upper[4], lower[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = k * 64 + lane;
+                    const bool valid = i < m_in;
+                    const float r = q0[k] * nx + q1[k] * ny + q2[k] * nz + nb;
+                    const int cls = huber_class(r, hr);
+                    if (valid) R[i] = r;
+                    noncore[k] = __ballot(valid && cls != 0);
+                    upper[k] = __ballot(valid && cls == 1);
+                    lower[k] = __ballot(valid && cls == 2);
+                }
+                wave_lds_sync();
+                const double acc = gn_ordered_sum(xc, yc, m_in, noncore, upper, lower, is_j, hr);
+                wave_lds_sync();
                 double H[16], J[4];
 #pragma unroll
                 for (int e = 0; e < 16; e++) H[e] = __shfl(acc, e); // H[col*4+row]: a = row, b = col
@@ -402,10 +563,8 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
             out.mean_depth = g.mean_depth;
             out.view_cos = g.view_cos;
             out.size = sqrtf(far2);
-            fitted = true;
         }
     }
-    (void)fitted;
     if (lane == 0) c->seeds[s] = out;
 }
 
@@ -489,35 +648,70 @@ __device__ __forceinline__ int block_scan_1024(int v, int &excl, int *s_wave /* 
 
 // ------------------------------------------------------------------------------ new surfels
 // initialize_surfels: seeds in index order -> ordered stream compaction by one workgroup.
+constexpr int kMaxSeedRounds = 64; // seeds <= 64 * 1024 (checked by dsm_create)
+
 __global__ __launch_bounds__(1024) void k_new_surfels(const DeviceCtx *__restrict__ c) {
-    __shared__ int s_wave[17];
+    __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     const FrameParams &fp = frame_params(c);
     const Intrinsics K = c->k;
-    int run = 0;
-    for (int base = 0; base < c->n_seed; base += 1024) {
-        const int s = base + threadIdx.x;
+    const int S = c->n_seed;
+    const int rounds = (S + 1023) / 1024;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    // pass 1: predicate of seed r*1024 + tid (all loads independent), per-wave counts
+    unsigned long long mine = 0;
+    for (int r = 0; r < rounds; r++) {
+        const int s = r * 1024 + threadIdx.x;
         bool spawn = false;
-        SeedView sd;
-        if (s < c->n_seed) {
+        if (s < S) {
             const dsm_seed *sp = &c->seeds[s];
-            sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
-            sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
-            sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+            SeedView sd;
+            sd.size = 0; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
+            sd.px = sd.py = sd.pz = 0;
+            sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = 0;
             spawn = seed_spawns(sd, sp->fused != 0);
         }
-        int excl;
-        const int total = block_scan_1024(spawn ? 1 : 0, excl, s_wave);
-        if (spawn) {
-            const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
-            dsm_surfel o;
-            o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
-            o.size = e.size; o.color = e.color; o.weight = e.weight;
-            o.update_times = e.update_times; o.last_update = e.last_update;
-            c->fresh[run + excl] = o;
-        }
-        run += total;
+        if (spawn) mine |= 1ull << r;
+        const unsigned long long m = __ballot(spawn);
+        if (lane == 0) s_cnt[r * 16 + wv] = __popcll(m);
     }
-    if (threadIdx.x == 0) c->n_new[0] = run;
+    __syncthreads();
+    // exclusive scan of the rounds*16 wave counts (seed order = round-major, then wave), by wave 0
+    if (wv == 0) {
+        int run = 0;
+        for (int base = 0; base < rounds * 16; base += 64) {
+            const int i = base + lane;
+            const int v = i < rounds * 16 ? s_cnt[i] : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (i < rounds * 16) s_cnt[i] = run + inc - v;
+            run += __shfl(inc, 63);
+        }
+        if (lane == 0) s_cnt[kMaxSeedRounds * 16] = run;
+    }
+    __syncthreads();
+    // pass 2: ordered write
+    for (int r = 0; r < rounds; r++) {
+        const bool spawn = (mine >> r) & 1ull;
+        const unsigned long long m = __ballot(spawn);
+        if (!spawn) continue;
+        const int s = r * 1024 + threadIdx.x;
+        const dsm_seed *sp = &c->seeds[s];
+        SeedView sd;
+        sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
+        sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
+        sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+        const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
+        dsm_surfel o;
+        o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
+        o.size = e.size; o.color = e.color; o.weight = e.weight;
+        o.update_times = e.update_times; o.last_update = e.last_update;
+        c->fresh[s_cnt[r * 16 + wv] + rank_below(m)] = o;
+    }
+    if (threadIdx.x == 0) c->n_new[0] = s_cnt[kMaxSeedRounds * 16];
 }
 
 // ------------------------------------------------------------------------------ hole scan

@@ -188,6 +188,20 @@ DSM_HD double gn_term_add(double acc, const GnTerm &t, const float p[4], float r
     return acc;
 }
 
+// The same sums in the form the HIP kernel streams them: residual class first, then one branch-free
+// term per (element, accumulator).  X,Y = (p_a, p_b) for H(a,b) and (r, p_a) for J(a).
+DSM_HD int huber_class(float r, double hr) {
+    if ((double)r < hr && (double)r > -1 * hr) return 0; // core
+    if ((double)r >= hr) return 1;                       // upper tail
+    if ((double)r <= -1 * hr) return 2;                  // lower tail
+    return 3;                                            // NaN: contributes nothing
+}
+DSM_HD double gn_term(bool is_jacobian, float X, float Y, int cls, double hr) {
+    const double core = (double)(2 * X * Y);
+    const double tail = (cls == 1 ? hr : -1 * hr) * (double)Y;
+    return cls == 0 ? core : ((is_jacobian && cls != 3) ? tail : 0.0);
+}
+
 // solve and apply one Gauss-Newton step, FF.cpp:172-180.  H column-major 4x4 (without damping).
 DSM_HD void gn_step(double *H, const double *J, float &nx, float &ny, float &nz, float &nb) {
     H[0] += 5; H[5] += 5; H[10] += 5; H[15] += 5;

@@ -196,15 +196,20 @@ void seed_planes(Emu &e) {
                 for (int i = 0; i < m; i++) { lp[i * 3] -= mx; lp[i * 3 + 1] -= my; lp[i * 3 + 2] -= mz; }
                 for (int it = 0; it < 5; it++) {
                     double acc[20];
+                    float res[256];
+                    int cls[256];
+                    for (int i = 0; i < m; i++) {
+                        res[i] = lp[i * 3] * nx + lp[i * 3 + 1] * ny + lp[i * 3 + 2] * nz + nb;
+                        cls[i] = huber_class(res[i], e.huber);
+                    }
                     for (int lane = 0; lane < 20; lane++) {
-                        GnTerm t;
-                        t.a = lane < 16 ? (lane & 3) : ((lane - 16) & 3);
-                        t.b = lane < 16 ? (lane >> 2) : -1;
+                        const bool is_j = lane >= 16;
+                        const int ta = lane < 16 ? (lane & 3) : ((lane - 16) & 3), tb = (lane >> 2) & 3;
                         double a = 0.0;
                         for (int i = 0; i < m; i++) {
-                            float p4[4] = {lp[i * 3], lp[i * 3 + 1], lp[i * 3 + 2], 1.0f};
-                            const float r = p4[0] * nx + p4[1] * ny + p4[2] * nz + nb;
-                            a = gn_term_add(a, t, p4, r, e.huber);
+                            const float p4[4] = {lp[i * 3], lp[i * 3 + 1], lp[i * 3 + 2], 1.0f};
+                            const float X = is_j ? res[i] : p4[ta], Y = is_j ? p4[ta] : p4[tb];
+                            a += gn_term(is_j, X, Y, cls[i], e.huber);
                         }
                         acc[lane] = a;
                     }
