@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "dsm_map_upload", "dsm_map_size", "dsm_map_download", "dsm_map_copy_to_device",
     "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
-    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed",
+    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps",
 )
 
 
@@ -108,6 +108,7 @@ def load_library():
     lib.dsm_get_labels.argtypes = [_vp, _vp]
     lib.dsm_get_seeds.argtypes = [_vp, _vp]
     lib.dsm_seed_count.argtypes = [_vp]
+    lib.dsm_debug_wave_stamps.argtypes = [_vp, _vp]
     lib.dsm_replay_timed.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.POINTER(_StageTimes)]
     _lib = lib
     return lib
@@ -276,6 +277,11 @@ class FusionFunctions:
     def seeds(self) -> np.ndarray:  # FusionFunctions::superpixel_seeds
         out = np.zeros(self.n_seed, SEED_DTYPE)
         self._check(self._lib.dsm_get_seeds(self._h, _ptr(out)))
+        return out
+
+    def debug_wave_stamps(self) -> np.ndarray:
+        out = np.zeros((4, self.n_seed, 8), np.int64)
+        self._check(self._lib.dsm_debug_wave_stamps(self._h, _ptr(out)))
         return out
 
     def replay_timed(self, slots, ref_idx, poses_cm):

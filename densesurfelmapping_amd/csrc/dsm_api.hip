@@ -101,6 +101,28 @@ int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16) {
     return DSM_OK;
 }
 
+// stage the params of up to n consecutive frames with one host-to-device copy; returns how many
+// were staged (limited by the ring's wrap-around point)
+int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t *ref_idx, const float *poses16, int *staged) {
+    const int ring = (int)(h->frames_submitted % kParamRing);
+    int m = n < kParamRing - ring ? n : kParamRing - ring;
+    if (m > kParamRing / 2) m = kParamRing / 2;
+    int rc = reserve_params(h, m);
+    if (rc) return rc;
+    for (int i = 0; i < m; i++) {
+        if (slots[i] < 0 || slots[i] >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slots[i], h->hc.n_slots);
+        FrameParams &fp = h->h_params[ring + i];
+        memcpy(fp.pose, poses16 + 16 * (size_t)i, sizeof fp.pose);
+        inverse4<float>(fp.pose, fp.inv); // FF.cpp:59
+        fp.ref_idx = ref_idx[i];
+        fp.slot = slots[i];
+        fp.pad[0] = fp.pad[1] = 0;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    *staged = m;
+    return DSM_OK;
+}
+
 int fuse_grid_bound(const dsm_handle *h) { return h->hc.cap; }
 
 int ensure_graph(dsm_handle *h, bool with_compaction) {
@@ -269,6 +291,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &dep, (size_t)c.slot_elems * c.n_slots));
     c.img_base = img; c.depth_base = dep;
     CREATE_TRY(dev_alloc(h, &c.label, (size_t)c.slot_elems));
+    CREATE_TRY(dev_alloc(h, &c.label_alt, (size_t)c.slot_elems));
     CREATE_TRY(dev_alloc(h, &c.cand, (size_t)c.slot_elems));
     CREATE_TRY(dev_alloc(h, &c.worklist, (size_t)c.slot_elems));
     CREATE_TRY(dev_alloc(h, &c.core, (size_t)c.n_seed));
@@ -286,7 +309,9 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     int32_t *scalars = nullptr; // work_count, n_local, n_local_next, n_new, n_holes, cursor, status
     CREATE_TRY(dev_alloc(h, &scalars, 64));
     c.work_count = scalars + 0; c.n_local = scalars + 8; c.n_local_next = scalars + 16; c.n_new = scalars + 24;
-    c.n_holes = scalars + 32; c.cursor = scalars + 40; c.status = scalars + 48;
+    c.n_holes = scalars + 32; c.cursor = scalars + 40; c.status = scalars + 48; c.assign_done = scalars + 56;
+    if (const char *e = getenv("DSM_WAVE_STAMPS"))
+        if (e[0] == '1') CREATE_TRY(dev_alloc(h, &c.stamps, (size_t)4 * c.n_seed * 8));
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
     CREATE_TRY(dev_alloc(h, &h->d_ctx, 1));
@@ -451,9 +476,12 @@ int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
     int rc = bind_device(h);
     if (rc) return rc;
-    for (int i = 0; i < n; i++) {
-        if ((rc = stage_params(h, slots[i], ref_idx[i], poses16 + 16 * (size_t)i))) return rc;
-        if ((rc = submit_frame(h, true))) return rc;
+    for (int i = 0; i < n;) {
+        int m = 0;
+        if ((rc = stage_params_batch(h, n - i, slots + i, ref_idx + i, poses16 + 16 * (size_t)i, &m))) return rc;
+        for (int j = 0; j < m; j++)
+            if ((rc = submit_frame(h, true))) return rc;
+        i += m;
     }
     return DSM_OK;
 }
@@ -492,6 +520,17 @@ int dsm_get_seeds(dsm_handle *h, dsm_seed *out) {
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->hc.seeds, (size_t)h->hc.n_seed * sizeof(dsm_seed), hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+
+// debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_WAVE_STAMPS=1)
+int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 4 * n_seed * 8 */) {
+    if (!h || !out) return DSM_E_INVALID;
+    if (!h->hc.stamps) return fail(h, DSM_E_STATE, "handle was created without DSM_WAVE_STAMPS=1");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->hc.stamps, (size_t)4 * h->hc.n_seed * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return DSM_OK;
 }
 

@@ -34,7 +34,9 @@ struct DeviceCtx {
     int64_t slot_elems; // pitch * h
     int32_t n_slots;
     // superpixel state
-    int32_t *label; // [h][pitch] current superpixel index of every pixel
+    int32_t *label; // [h][pitch] superpixel index of every pixel (final; sweeps ping-pong with label_alt)
+    int32_t *label_alt;
+    int32_t *assign_done; // block ticket of k_assign (the last block to finish runs the resolve step)
     int32_t *cand;  // [h][pitch] seed picked by this sweep before the stable-skip rule is applied
     float4 *core;   // [S] x, y, mean_intensity, mean_depth  (live seed state during the sweeps)
     double *inv_depth; // [S] 1.0 / mean_depth, FF.cpp:380
@@ -63,6 +65,13 @@ struct DeviceCtx {
     int32_t n_params;
     int32_t *cursor;
     int32_t *status; // sticky device-side error bits
+    // the frame being processed: written by k_init_seeds (first kernel of a frame) from
+    // params[cursor % n_params], read by every later kernel of the frame with one scalar load
+    FrameParams cur;
+    const uint8_t *cur_img;
+    const float *cur_dep;
+    // optional per-wave phase stamps (shader clock) of the per-seed kernels; null unless DSM_WAVE_STAMPS=1
+    long long *stamps; // [4 kernels][n_seed][8]
 };
 
 constexpr int kStatusCapacity = 1;
@@ -71,7 +80,7 @@ constexpr int kStatusBadPick = 2;
 // launch all kernels of one frame on `stream`.  with_compaction: SurfelMap::fuse_map semantics,
 // otherwise FusionFunctions::fuse_initialize_map.  If ev != nullptr, an event is recorded before
 // the first kernel and after every kernel (ev[0..n_stages]).
-constexpr int kNumStages = 20;
+constexpr int kNumStages = 15;
 extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx *d_ctx, const DeviceCtx &h_ctx, int map_upper_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev);

@@ -25,15 +25,31 @@ __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 __device__ __forceinline__ int rank_below(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// Wave-wide integer sum / float max by DPP (no LDS crossbar): Hillis-Steele within each row of 16
+// (row_shr 1,2,4,8), then row_bcast15 / row_bcast31 carry the row totals; lane 63 ends with the total.
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
 }
+// v >= 0 in every lane (identity +0.0f)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+#define DSM_DPP_MAX(ctrl, rows) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false)))
+    DSM_DPP_MAX(0x111, 0xf); DSM_DPP_MAX(0x112, 0xf); DSM_DPP_MAX(0x114, 0xf); DSM_DPP_MAX(0x118, 0xf);
+    DSM_DPP_MAX(0x142, 0xa); DSM_DPP_MAX(0x143, 0xc);
+#undef DSM_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// value of a double held by lane `src` (compile-time constant), as a wave-uniform scalar
+__device__ __forceinline__ double read_lane_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // order LDS traffic of one wave: a lane's reads after this see every lane's writes before it
 // (the LDS queue of a wave is FIFO; this only stops the compiler from moving accesses across).
@@ -59,29 +75,70 @@ __device__ __forceinline__ float ordered_sum(const float *l, int n) {
     }
     return a;
 }
+// six independent ordered sums over columns of equal (padded) length, interleaved for ILP
+__device__ __forceinline__ void ordered_sum6(const float *c0, const float *c1, const float *c2, const float *c3,
+                                             const float *c4, const float *c5, int n, float out[6]) {
+    const float *col[6] = {c0, c1, c2, c3, c4, c5};
+    float a[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i += 8) {
+        float4 u[6], v[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            u[q] = *reinterpret_cast<const float4 *>(col[q] + i);
+            v[q] = *reinterpret_cast<const float4 *>(col[q] + i + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += u[q].x;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += u[q].y;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += u[q].z;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += u[q].w;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += v[q].x;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += v[q].y;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += v[q].z;
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += v[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) out[q] = a[q];
+}
 // zero the padding slots [n, round_up(n, 8)) of a column
 __device__ __forceinline__ void pad_column(float *l, int n, int lane) {
     if (lane < 8 && n + lane < ((n + 7) & ~7)) l[n + lane] = 0.0f;
 }
 
-__device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) {
-    return c->params[(unsigned)c->cursor[0] % (unsigned)c->n_params];
+// debug: record the shader clock of phase `ph` of seed s in per-seed kernel `kid` (lane 0 only)
+__device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph, int lane) {
+    if (c->stamps && lane == 0) c->stamps[((int64_t)kid * c->n_seed + s) * 8 + ph] = clock64();
 }
-__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &fp) {
-    return c->img_base + (int64_t)fp.slot * c->slot_elems;
-}
-__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &fp) {
-    return c->depth_base + (int64_t)fp.slot * c->slot_elems;
-}
+
+__device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur; }
+__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return c->cur_img; }
+__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur_dep; }
 
 // ------------------------------------------------------------------------------ init seeds
 __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx *__restrict__ c) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
     if (s == 0) c->work_count[0] = 0;
-    const FrameParams &fp = frame_params(c);
-    const uint8_t *img = frame_image(c, fp);
-    const float *dep = frame_depth(c, fp);
+    // first kernel of the frame: resolve the params ring once and publish the result in the context
+    const FrameParams &fp = c->params[(unsigned)c->cursor[0] % (unsigned)c->n_params];
+    const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
+    const float *dep = c->depth_base + (int64_t)fp.slot * c->slot_elems;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        DeviceCtx *wc = const_cast<DeviceCtx *>(c);
+        const int t = threadIdx.x;
+        if (t < 16) wc->cur.pose[t] = fp.pose[t];
+        else if (t < 32) wc->cur.inv[t - 16] = fp.inv[t - 16];
+        else if (t == 32) { wc->cur.ref_idx = fp.ref_idx; wc->cur.slot = fp.slot; }
+        else if (t == 33) wc->cur_img = img;
+        else if (t == 34) wc->cur_dep = dep;
+    }
     const int w = c->w, h = c->h, pitch = c->pitch;
     const bool live = s < c->n_seed;
     int gx = 0, gy = 0, ix = 0, iy = 0;
@@ -140,12 +197,38 @@ __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx *__restrict_
 // tmin (see k_resolve).
 constexpr int kTileW = 64, kTileH = 4, kTileCellsX = kTileW / kCell + 2, kTileCellsY = 3;
 
-template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx *__restrict__ c) {
+// The reference scans pixels in row-major order; a pixel is skipped iff its current seed is still
+// `stable` when the scan reaches it, and every evaluated pixel clears `stable` of the seed it
+// picks.  With T[s] = first pixel key at which s is cleared this reads
+//     evaluated(p)  <=>  T[label(p)] < p ,      T[s] = min { p : evaluated(p), pick(p) = s } ,
+// whose least fixed point from above (T = -1 for unstable seeds, +inf for stable ones) is reached
+// by repeated atomicMin.  Every pixel whose seed was unstable applies its own atomicMin directly;
+// only pixels whose old and new seeds were both stable (a short list: borders between two seeds
+// that stopped moving) can still change the picture; k_resolve iterates that list to the fixed point.
+__device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
+    const int n = c->work_count[0];
+    if (n == 0) return;
+    for (;;) {
+        int changed = 0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int p = c->worklist[i];
+            const int l = label_in[p], pk = c->cand[p];
+            if (load_coherent(&c->tmin[l]) < p && load_coherent(&c->tmin[pk]) > p) {
+                atomicMin(&c->tmin[pk], p);
+                changed = 1;
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+}
+
+template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx *__restrict__ c, int sweep) {
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
+    const int32_t *label_in = ((sweep - 1) & 1) ? c->label_alt : c->label; // sweep >= 1
     const int w = c->w, h = c->h, pitch = c->pitch, gw = c->gw, gh = c->gh;
     const int bx = blockIdx.x * kTileW, by = blockIdx.y * kTileH;
     const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
@@ -159,74 +242,47 @@ template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const Devi
     }
     __syncthreads();
     const int x = bx + (tid & (kTileW - 1)), y = by + tid / kTileW;
-    if (x >= w || y >= h) return;
-    const int p = y * pitch + x;
-    const float pix_i = (float)img[p];
-    const float pix_d = dep[p];
-    const int pick = pick_seed(x, y, pix_i, pix_d, gw, gh,
-                               [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
-                                   const int li = (gy - cy0) * kTileCellsX + (gx - cx0);
-                                   const float4 v = s_core[li];
-                                   sx = v.x; sy = v.y; si = v.z;
-                                   has_d = v.w > 0;
-                                   inv_d = s_inv[li];
-                               });
-    if (pick < 0) { // only for image sizes the reference itself mishandles; rejected by dsm_create
-        atomicOr(c->status, kStatusBadPick);
-        if (FIRST) c->label[p] = 0; else c->cand[p] = c->label[p];
-        return;
-    }
-    if (FIRST) {
-        c->label[p] = pick;
-        return;
-    }
-    c->cand[p] = pick;
-    const int l = c->label[p];
-    const int tl = c->tmin[l]; // -1 never changes; >= 0 only moves among values >= 0
-    if (tl == -1) {
-        // the old seed was unstable at sweep start: this pixel is evaluated whatever happens
-        // elsewhere, so its pick loses `stable` no later than at p
-        if (load_coherent(&c->tmin[pick]) > p) atomicMin(&c->tmin[pick], p);
-    } else if (pick != l && c->tmin[pick] != -1) {
-        // old and new seed both stable at sweep start: whether this pixel is evaluated depends on
-        // the scan order -- leave it to k_resolve
-        const int slot = atomicAdd(c->work_count, 1);
-        c->worklist[slot] = p;
-    }
-}
-
-// ------------------------------------------------------------------------------ resolve
-// The reference scans pixels in row-major order; a pixel is skipped iff its current seed is still
-// `stable` when the scan reaches it, and every evaluated pixel clears `stable` of the seed it
-// picks.  With T[s] = first pixel key at which s is cleared this reads
-//     evaluated(p)  <=>  T[label(p)] < p ,      T[s] = min { p : evaluated(p), pick(p) = s } ,
-// whose least fixed point from above (T = -1 for unstable seeds, +inf for stable ones) is reached
-// by repeated atomicMin.  k_assign already applied every pixel whose seed was unstable; only the
-// pixels in the worklist can still change the picture.  One workgroup iterates them to the fixed
-// point (the list is short: borders between two seeds that both stopped moving).
-__global__ __launch_bounds__(1024) void k_resolve(const DeviceCtx *__restrict__ c) {
-    const int n = c->work_count[0];
-    if (n == 0) return;
-    for (;;) {
-        int changed = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            const int p = c->worklist[i];
-            const int l = c->label[p], pk = c->cand[p];
-            if (load_coherent(&c->tmin[l]) < p && load_coherent(&c->tmin[pk]) > p) {
-                atomicMin(&c->tmin[pk], p);
-                changed = 1;
+    if (x < w && y < h) {
+        const int p = y * pitch + x;
+        const float pix_i = (float)img[p];
+        const float pix_d = dep[p];
+        int l = 0;
+        if (!FIRST) l = label_in[p];
+        const int pick = pick_seed(x, y, pix_i, pix_d, gw, gh,
+                                   [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
+                                       const int li = (gy - cy0) * kTileCellsX + (gx - cx0);
+                                       const float4 v = s_core[li];
+                                       sx = v.x; sy = v.y; si = v.z;
+                                       has_d = v.w > 0;
+                                       inv_d = s_inv[li];
+                                   });
+        if (pick < 0) { // every candidate cost >= the reference's 1e6 sentinel: it would index seeds[-1]
+            atomicOr(c->status, kStatusBadPick);
+            if (FIRST) c->label[p] = 0; else c->cand[p] = l;
+        } else if (FIRST) {
+            c->label[p] = pick;
+        } else {
+            c->cand[p] = pick;
+            const int tl = c->tmin[l]; // -1 never changes; >= 0 only moves among values >= 0
+            if (tl == -1) {
+                // the old seed was unstable at sweep start: this pixel is evaluated whatever happens
+                // elsewhere, so its pick loses `stable` no later than at p
+                if (load_coherent(&c->tmin[pick]) > p) atomicMin(&c->tmin[pick], p);
+            } else if (pick != l && c->tmin[pick] != -1) {
+                // old and new seed both stable at sweep start: whether this pixel is evaluated depends
+                // on the scan order -- resolved below
+                const int slot = atomicAdd(c->work_count, 1);
+                c->worklist[slot] = p;
             }
         }
-        if (!__syncthreads_or(changed)) break;
     }
 }
 
-__global__ __launch_bounds__(256) void k_apply(const DeviceCtx *__restrict__ c) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= c->w) return;
-    const int p = y * c->pitch + x;
-    const int l = c->label[p];
-    if (c->tmin[l] < p) c->label[p] = c->cand[p];
+// One workgroup iterates the worklist to the fixed point.  (Folding this into k_assign behind a
+// "last block done" ticket costs a device-scope release per workgroup -- an L2 write-back on this
+// multi-XCD part -- and was 10x slower than the extra launch.)
+__global__ __launch_bounds__(256) void k_resolve(const DeviceCtx *__restrict__ c, int sweep) {
+    resolve_worklist(c, ((sweep - 1) & 1) ? c->label_alt : c->label);
 }
 
 // Ordered sum of one Huber-Newton pass (FF.cpp:536-549): element i adds lt[i] = 2*r if its residual is
@@ -250,8 +306,9 @@ __device__ __forceinline__ float huber_ordered_sum(const float *lt, int nd, cons
                 const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    if ((t8 >> q) & 1u) a = (float)((double)a + (((p8 >> q) & 1u) ? hr : -1 * hr));
-                    else a += e[q];
+                    const float a_core = a + e[q];
+                    const float a_tail = (float)((double)a + (((p8 >> q) & 1u) ? hr : -1 * hr));
+                    a = ((t8 >> q) & 1u) ? a_tail : a_core;
                 }
             }
         }
@@ -266,50 +323,89 @@ __device__ __forceinline__ float huber_ordered_sum(const float *lt, int nd, cons
 // so member depths are compacted in order into LDS and summed sequentially.
 constexpr int kWin = 2 * kCell; // 16
 
-__global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restrict__ c, int sweep) {
+// APPLY (sweeps >= 1): the label image of this sweep is  new(p) = T[old(p)] < p ? pick(p) : old(p)  (see
+// k_assign); it is formed on the fly for the window, and every wave stores it for the pixels of its
+// own cell (ragged right/bottom pixels go to the last cell column/row) into the other label buffer.
+template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restrict__ c, int sweep) {
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = blockIdx.x * 4 + wv;
     if (s >= c->n_seed) return;
-    if (c->tmin[s] == kIntMax) return; // stable: FF.cpp:479-480
+    stamp(c, sweep, s, 0, lane);
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
+    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
+    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
     const int w = c->w, h = c->h, pitch = c->pitch;
-    const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
+    const int gx = s % c->gw, gy = s / c->gw;
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+    const int t_self = c->tmin[s];
     float *dl = s_depth[wv], *lt = s_term[wv];
-    int cnt = 0, sx = 0, sy = 0, si = 0, nd = 0;
+    stamp(c, sweep, s, 1, lane);
+    int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
+    int lab[4], pi[4], cd[4], pk[4];
+    float pd[4];
+    bool pimg[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // independent loads, one round trip
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        pimg[k] = x >= 0 && x < w && y >= 0 && y < h;
+        pk[k] = pimg[k] ? y * pitch + x : 0;
+        lab[k] = label_in[pk[k]];
+        if (APPLY) cd[k] = c->cand[pk[k]];
+        pd[k] = dep[pk[k]];
+        pi[k] = (int)img[pk[k]];
+    }
+    if (APPLY) {
+        int tl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tl[k] = c->tmin[lab[k]];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = k * 64 + lane;
+            const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+            if (tl[k] < pk[k]) lab[k] = cd[k];
+            const int ox = (x >> 3) < c->gw ? (x >> 3) : c->gw - 1, oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
+            if (pimg[k] && ox == gx && oy == gy) label_out[pk[k]] = lab[k];
+        }
+    }
+    if (t_self == kIntMax) return; // stable: FF.cpp:479-480
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int idx = k * 64 + lane;
         const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        // window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
-        const bool in = x >= 0 && x < w - 1 && y >= 0 && y < h - 1;
-        const int p = y * pitch + x;
-        const bool mem = in && c->label[p] == s;
-        float d = 0.0f;
+        // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
+        const bool mem = pimg[k] && x < w - 1 && y < h - 1 && lab[k] == s;
+        const float d = mem ? pd[k] : 0.0f;
         if (mem) {
-            d = dep[p];
-            cnt += 1; sx += x; sy += y; si += (int)img[p];
+            cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += pi[k];
         }
         const bool dv = mem && (double)d > 0.1; // FF.cpp:508
         const unsigned long long m = __ballot(dv);
         if (dv) dl[nd + rank_below(m)] = d;
         nd += __popcll(m);
     }
+    stamp(c, sweep, s, 2, lane);
     cnt = wave_sum(cnt);
     if (cnt == 0) { // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
         if (lane == 0) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(c->n_seed, s)], s);
         return;
     }
-    sx = wave_sum(sx); sy = wave_sum(sy); si = wave_sum(si);
+    // integer sums (exact in the reference's fp32 accumulators): offsets within the window are summed
+    // 12 bits each in one word, then shifted back by cnt * window origin
+    const int packed = wave_sum(sdx | (sdy << 16));
+    si = wave_sum(si);
+    const int sx = (packed & 0xffff) + cnt * wx0, sy = (packed >> 16) + cnt * wy0;
     wave_lds_sync();
     const float fn = (float)cnt;
     const float mi = (float)si / fn, mx = (float)sx / fn, my = (float)sy / fn;
     const float4 old = c->core[s];
     const float moved = fabsf(old.z - mi) + fabsf(old.x - mx) + fabsf(old.y - my);
     const int stable = (double)moved < 0.2 ? 1 : 0;
+    stamp(c, sweep, s, 3, lane);
     float md = 0.0f;
     if (nd > 0) {
         // FF.cpp:530-556.  The loop-carried part of a Huber-Newton pass is only the ordered fp32 sum of
@@ -319,14 +415,17 @@ __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restric
         pad_column(lt, nd, lane); // pad slots stay +0.0f: the passes below only write valid slots
         wave_lds_sync();
         md = ordered_sum(dl, nd) / (float)nd;
+        stamp(c, sweep, s, 4, lane);
         float dk[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) dk[k] = (k * 64 + lane < nd) ? dl[k * 64 + lane] : 0.0f;
+        const int nk = (nd + 63) >> 6;
         for (int it = 0; it < 5; it++) {
-            unsigned long long tail[4], pos[4];
+            unsigned long long tail[4] = {0, 0, 0, 0}, pos[4] = {0, 0, 0, 0};
             int n_core = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                if (k >= nk) break;
                 const int idx = k * 64 + lane;
                 const bool valid = idx < nd;
                 const float r = md - dk[k];
@@ -345,6 +444,8 @@ __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restric
             if ((double)delta < 0.01 && (double)delta > -0.01) break;
         }
     }
+    stamp(c, sweep, s, 5, lane);
+    if (c->stamps && lane == 0) c->stamps[((int64_t)sweep * c->n_seed + s) * 8 + 7] = nd;
     if (lane == 0) {
         c->core_stage[s] = make_float4(mx, my, mi, md);
         c->stable_stage[s] = stable;
@@ -380,6 +481,9 @@ __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx *__restric
 //     J(a)   += +-hr*(double)p_a                                      (Huber tails)
 // i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}.
 constexpr int kCols = 10; // LDS columns per wave: p0 p1 p2 r ones | n0 n1 n2 | depth | packed xy
+// column stride: 260 floats shifts successive columns by 4 banks, so that lanes streaming different
+// columns at the same element offset (ds_read_b128) do not collide
+constexpr int kColStride = kWin * kWin + 4;
 
 // Ordered double sum of one accumulator over the (padded) inlier list.  Blocks of 8 whose residuals are
 // all in the Huber core take the plain path; otherwise the class of each element comes from the
@@ -418,13 +522,14 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
 }
 
 __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict__ c) {
-    __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kWin * kWin];
+    __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = blockIdx.x * 4 + wv;
     if (s >= c->n_seed) return;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
+    stamp(c, 3, s, 0, lane);
     const Intrinsics K = c->k;
     const double hr = c->huber;
     const float4 core = c->core[s];
@@ -437,16 +542,25 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
     // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
     int n = 0;
     float far2 = 0.0f;
+    int lab[4];
+    float pd[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // 8 independent loads, one round trip
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        const bool in = x >= 0 && x < w && y >= 0 && y < h;
+        const int p = in ? y * pitch + x : 0;
+        lab[k] = in ? c->label[p] : -1;
+        pd[k] = dep[p];
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int idx = k * 64 + lane;
         const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        const bool in = x >= 0 && x < w && y >= 0 && y < h;
-        const int p = y * pitch + x;
-        const bool mem = in && c->label[p] == s;
+        const bool mem = lab[k] == s;
         float d = 0.0f;
         if (mem) {
-            d = dep[p];
+            d = pd[k];
             const float ex = (float)x - core.x, ey = (float)y - core.y;
             const float d2 = ex * ex + ey * ey;
             if (d2 > far2) far2 = d2;
@@ -462,6 +576,7 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
     }
     far2 = wave_max(far2);
     wave_lds_sync();
+    stamp(c, 3, s, 1, lane);
 
     dsm_seed out;
     out.x = core.x; out.y = core.y;
@@ -481,13 +596,18 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
         int m_in = 0;
         for (int base = 0; base < n; base += 64) {
             const int i = base + lane;
-            bool ok = false;
-            float d = 0.0f;
+            bool ok = false, interior = false;
+            float d = 0.0f, d_right = 0.0f, d_down = 0.0f;
             int x = 0, y = 0;
             if (i < n) {
                 d = ld[i];
                 const int xy = lxy[i];
                 x = xy & 0xffff; y = xy >> 16;
+                interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2; // FF.cpp:670-677
+                if (interior) { // neighbours for the forward differences, fetched before they are known to be needed
+                    d_right = dep[y * pitch + x + 1];
+                    d_down = dep[(y + 1) * pitch + x];
+                }
                 const float r = md - d;
                 ok = (double)r < hr && (double)r > -hr;
             }
@@ -495,8 +615,7 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
             if (ok) {
                 const int pos = m_in + rank_below(m);
                 float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-                if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) // FF.cpp:670-677
-                    pixel_normal(K, x, y, d, dep[y * pitch + x + 1], dep[(y + 1) * pitch + x], nx, ny, nz);
+                if (interior) pixel_normal(K, x, y, d, d_right, d_down, nx, ny, nz);
                 N0[pos] = nx; N1[pos] = ny; N2[pos] = nz;
                 float px, py, pz;
                 back_project(K, (float)x, (float)y, d, px, py, pz);
@@ -509,10 +628,13 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
         pad_column(R, m_in, lane); pad_column(ONE, m_in, lane);
         pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
         wave_lds_sync();
+        stamp(c, 3, s, 2, lane);
         if (!((double)((float)m_in / (float)n) < 0.8)) { // FF.cpp:862
             // sequential fp32 sums, FF.cpp:852-857 and 111-116
-            float nx = ordered_sum(N0, m_in), ny = ordered_sum(N1, m_in), nz = ordered_sum(N2, m_in), nb = 0;
-            float mx = ordered_sum(P0, m_in), my = ordered_sum(P1, m_in), mz = ordered_sum(P2, m_in);
+            float sums[6];
+            ordered_sum6(N0, N1, N2, P0, P1, P2, m_in, sums);
+            float nx = sums[0], ny = sums[1], nz = sums[2], nb = 0;
+            float mx = sums[3], my = sums[4], mz = sums[5];
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
             nx = nx / len; ny = ny / len; nz = nz / len;
             mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
@@ -527,16 +649,19 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
                     P0[i] = q0[k]; P1[i] = q1[k]; P2[i] = q2[k];
                 }
             }
+            stamp(c, 3, s, 3, lane);
             // operand columns of this lane's accumulator
             const bool is_j = lane >= 16;
             const int ta = lane < 16 ? (lane & 3) : ((lane - 16) & 3), tb = (lane >> 2) & 3;
             const int xs = is_j ? 4 : ta, ys = is_j ? ta : tb; // 0..2 = p, 3 = ones, 4 = r
             const float *xc = xs == 0 ? P0 : xs == 1 ? P1 : xs == 2 ? P2 : xs == 3 ? ONE : R;
             const float *yc = ys == 0 ? P0 : ys == 1 ? P1 : ys == 2 ? P2 : ONE;
+            const int mk = (m_in + 63) >> 6;
             for (int it = 0; it < 5; it++) {
-                unsigned long long noncore[4], upper[4], lower[4];
+                unsigned long long noncore[4] = {0, 0, 0, 0}, upper[4] = {0, 0, 0, 0}, lower[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
+                    if (k >= mk) break;
                     const int i = k * 64 + lane;
                     const bool valid = i < m_in;
                     const float r = q0[k] * nx + q1[k] * ny + q2[k] * nz + nb;
@@ -551,11 +676,12 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
                 wave_lds_sync();
                 double H[16], J[4];
 #pragma unroll
-                for (int e = 0; e < 16; e++) H[e] = __shfl(acc, e); // H[col*4+row]: a = row, b = col
+                for (int e = 0; e < 16; e++) H[e] = read_lane_f64(acc, e); // H[col*4+row]: a = row, b = col
 #pragma unroll
-                for (int e = 0; e < 4; e++) J[e] = __shfl(acc, 16 + e);
+                for (int e = 0; e < 4; e++) J[e] = read_lane_f64(acc, 16 + e);
                 gn_step(H, J, nx, ny, nz, nb);
             }
+            stamp(c, 3, s, 4, lane);
             plane_finish(nx, ny, nz, nb, mx, my, mz);
             const SeedGeom g = seed_geometry(K, core.x, core.y, md, nx, ny, nz, nb);
             out.norm_x = g.nx; out.norm_y = g.ny; out.norm_z = g.nz;
@@ -565,6 +691,8 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
             out.size = sqrtf(far2);
         }
     }
+    stamp(c, 3, s, 5, lane);
+    if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
     if (lane == 0) c->seeds[s] = out;
 }
 
@@ -650,29 +778,39 @@ __device__ __forceinline__ int block_scan_1024(int v, int &excl, int *s_wave /* 
 // initialize_surfels: seeds in index order -> ordered stream compaction by one workgroup.
 constexpr int kMaxSeedRounds = 64; // seeds <= 64 * 1024 (checked by dsm_create)
 
-__global__ __launch_bounds__(1024) void k_new_surfels(const DeviceCtx *__restrict__ c) {
-    __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
+__device__ __forceinline__ void tail_new_surfels(const DeviceCtx *__restrict__ c, int *s_cnt /* [kMaxSeedRounds*16+1] */) {
     const FrameParams &fp = frame_params(c);
     const Intrinsics K = c->k;
     const int S = c->n_seed;
     const int rounds = (S + 1023) / 1024;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    // pass 1: predicate of seed r*1024 + tid (all loads independent), per-wave counts
+    // pass 1: predicate of seed r*1024 + tid, per-wave counts; the loads of 8 rounds are issued together
     unsigned long long mine = 0;
-    for (int r = 0; r < rounds; r++) {
-        const int s = r * 1024 + threadIdx.x;
-        bool spawn = false;
-        if (s < S) {
-            const dsm_seed *sp = &c->seeds[s];
-            SeedView sd;
-            sd.size = 0; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
-            sd.px = sd.py = sd.pz = 0;
-            sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = 0;
-            spawn = seed_spawns(sd, sp->fused != 0);
+    for (int r0 = 0; r0 < rounds; r0 += 8) {
+        float f_md[8], f_vc[8], f_nx[8], f_ny[8], f_nz[8];
+        unsigned char f_fu[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int s = (r0 + q) * 1024 + threadIdx.x;
+            const dsm_seed *sp = &c->seeds[s < S ? s : 0];
+            f_md[q] = sp->mean_depth; f_vc[q] = sp->view_cos;
+            f_nx[q] = sp->norm_x; f_ny[q] = sp->norm_y; f_nz[q] = sp->norm_z;
+            f_fu[q] = sp->fused;
         }
-        if (spawn) mine |= 1ull << r;
-        const unsigned long long m = __ballot(spawn);
-        if (lane == 0) s_cnt[r * 16 + wv] = __popcll(m);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int r = r0 + q;
+            if (r >= rounds) break;
+            const int s = r * 1024 + threadIdx.x;
+            SeedView sd;
+            sd.size = 0; sd.nx = f_nx[q]; sd.ny = f_ny[q]; sd.nz = f_nz[q];
+            sd.px = sd.py = sd.pz = 0;
+            sd.view_cos = f_vc[q]; sd.mean_depth = f_md[q]; sd.mean_intensity = 0;
+            const bool spawn = s < S && seed_spawns(sd, f_fu[q] != 0);
+            if (spawn) mine |= 1ull << r;
+            const unsigned long long m = __ballot(spawn);
+            if (lane == 0) s_cnt[r * 16 + wv] = __popcll(m);
+        }
     }
     __syncthreads();
     // exclusive scan of the rounds*16 wave counts (seed order = round-major, then wave), by wave 0
@@ -716,8 +854,7 @@ __global__ __launch_bounds__(1024) void k_new_surfels(const DeviceCtx *__restric
 
 // ------------------------------------------------------------------------------ hole scan
 // Ascending list of deleted slots (SM.cpp:1078-1083) from the per-wave bitmaps.
-__global__ __launch_bounds__(1024) void k_hole_scan(const DeviceCtx *__restrict__ c) {
-    __shared__ int s_wave[17];
+__device__ __forceinline__ void tail_hole_scan(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */) {
     const int M = c->n_local[0];
     const int n_word = (M + 63) >> 6;
     int run = 0;
@@ -757,9 +894,9 @@ __device__ __forceinline__ bool is_hole(const DeviceCtx *c, int i, int &rank) {
     return (m >> b) & 1ull;
 }
 
-__global__ __launch_bounds__(256) void k_compact(const DeviceCtx *__restrict__ c) {
-    const int M = c->n_local[0], K = c->n_new[0], k = c->n_holes[0];
-    const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+__device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c) {
+    const int M = c->n_local[0], K = load_coherent(c->n_new), k = load_coherent(c->n_holes);
+    const int tid = threadIdx.x, nthr = 1024;
     dsm_surfel *local = c->local;
     const dsm_surfel *fresh = c->fresh;
     int new_m;
@@ -789,9 +926,22 @@ __global__ __launch_bounds__(256) void k_compact(const DeviceCtx *__restrict__ c
     if (tid == 0) c->n_local_next[0] = new_m;
 }
 
-// advance to the next frame: commit the map size, bump the params cursor
-__global__ void k_end_frame(const DeviceCtx *__restrict__ c, int with_compaction) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+// Frame tail in one workgroup: new surfels (ordered), deleted-slot list, order-exact compaction, then
+// commit the map size and bump the params cursor.  The phases are separated by a workgroup-scope fence +
+// barrier because later phases read what earlier ones (same workgroup) wrote to global memory.
+__global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx *__restrict__ c, int with_compaction) {
+    __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
+    __shared__ int s_wave[17];
+    tail_new_surfels(c, s_cnt);
+    if (with_compaction) {
+        tail_hole_scan(c, s_wave);
+        __threadfence_block(); // same workgroup, same CU: no device-scope write-back needed
+        __syncthreads();
+        tail_compact(c);
+    }
+    __threadfence_block(); // same workgroup, same CU: no device-scope write-back needed
+    __syncthreads();
+    if (threadIdx.x == 0) {
         if (with_compaction) c->n_local[0] = c->n_local_next[0];
         c->cursor[0] = c->cursor[0] + 1;
     }
@@ -809,9 +959,8 @@ __global__ void k_delay(long long ticks) {
 
 // ------------------------------------------------------------------------------ launcher
 const char *const kStageNames[kNumStages] = {
-    "init_seeds",   "assign_0",  "update_seeds_0", "commit_seeds_0", "assign_1",     "resolve_1",  "apply_1",
-    "update_seeds_1", "commit_seeds_1", "assign_2", "resolve_2",     "apply_2",      "update_seeds_2", "commit_seeds_2",
-    "seed_planes",  "fuse_surfels", "new_surfels", "hole_scan",      "compact",      "end_frame",
+    "init_seeds", "assign_0",  "update_seeds_0", "commit_seeds_0", "assign_1",    "resolve_1",    "update_seeds_1", "commit_seeds_1",
+    "assign_2",   "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_planes", "fuse_surfels", "frame_tail",
 };
 
 hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
@@ -829,25 +978,24 @@ hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_b
     const int S = hc.n_seed;
     const dim3 g_seed_thr((S + 255) / 256), g_seed_wave((S + 3) / 4);
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
-    const dim3 g_row((hc.w + 255) / 256, hc.h);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
     hipLaunchKernelGGL(k_init_seeds, g_seed_thr, dim3(256), 0, st, d);
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
-            hipLaunchKernelGGL(k_assign<true>, g_tile, dim3(256), 0, st, d);
+            hipLaunchKernelGGL(k_assign<true>, g_tile, dim3(256), 0, st, d, sweep);
+            DSM_MARK();
+            hipLaunchKernelGGL(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, d, sweep);
             DSM_MARK();
         } else {
-            hipLaunchKernelGGL(k_assign<false>, g_tile, dim3(256), 0, st, d);
+            hipLaunchKernelGGL(k_assign<false>, g_tile, dim3(256), 0, st, d, sweep);
             DSM_MARK();
-            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, st, d);
+            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(256), 0, st, d, sweep);
             DSM_MARK();
-            hipLaunchKernelGGL(k_apply, g_row, dim3(256), 0, st, d);
+            hipLaunchKernelGGL(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, d, sweep);
             DSM_MARK();
         }
-        hipLaunchKernelGGL(k_update_seeds, g_seed_wave, dim3(256), 0, st, d, sweep);
-        DSM_MARK();
         hipLaunchKernelGGL(k_commit_seeds, g_seed_thr, dim3(256), 0, st, d, sweep);
         DSM_MARK();
     }
@@ -858,18 +1006,7 @@ hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_b
     if (fuse_blocks > 2048) fuse_blocks = 2048;
     hipLaunchKernelGGL(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, d);
     DSM_MARK();
-    hipLaunchKernelGGL(k_new_surfels, dim3(1), dim3(1024), 0, st, d);
-    DSM_MARK();
-    if (with_compaction) {
-        hipLaunchKernelGGL(k_hole_scan, dim3(1), dim3(1024), 0, st, d);
-        DSM_MARK();
-        hipLaunchKernelGGL(k_compact, dim3(64), dim3(256), 0, st, d);
-        DSM_MARK();
-    } else {
-        DSM_MARK();
-        DSM_MARK();
-    }
-    hipLaunchKernelGGL(k_end_frame, dim3(1), dim3(64), 0, st, d, with_compaction ? 1 : 0);
+    hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1024), 0, st, d, with_compaction ? 1 : 0);
     DSM_MARK();
 #undef DSM_MARK
     return hipGetLastError();

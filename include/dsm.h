@@ -148,6 +148,10 @@ int dsm_get_labels(dsm_handle *h, int32_t *out /* height*width */);
 int dsm_get_seeds(dsm_handle *h, dsm_seed *out /* (width/8)*(height/8) */);
 int dsm_seed_count(const dsm_handle *h);
 
+/* debug tap: shader-clock stamps of the phases of the per-seed kernels, [4][n_seed][8] (kernel 0..2 =
+ * update_seeds of sweep 0..2, 3 = seed_planes); needs DSM_WAVE_STAMPS=1 in the environment at dsm_create */
+int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out);
+
 /* ---- per-kernel timing (hip events on the handle's stream) ----------------------------- */
 #define DSM_MAX_STAGES 32
 typedef struct dsm_stage_times {
