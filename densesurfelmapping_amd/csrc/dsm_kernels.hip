@@ -480,7 +480,12 @@ __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx *__restric
 //     H(a,b) += (double)((2*p_a)*p_b),  J(a) += (double)((2*r)*p_a)   (p_3 = 1; core residuals)
 //     J(a)   += +-hr*(double)p_a                                      (Huber tails)
 // i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}.
-constexpr int kCols = 10; // LDS columns per wave: p0 p1 p2 r ones | n0 n1 n2 | depth | packed xy
+constexpr int kCols = 6; // LDS columns per wave, reused across phases:
+//   gather / inlier phase:  depth list | packed xy | -       | n0       | n1   | n2
+//   sums phase:             p0         | p1        | p2      | n0       | n1   | n2
+//   Gauss-Newton phase:     p0         | p1        | p2      | residual | ones | solver scratch
+// (p0/p1 overwrite the depth/xy lists in place: a chunk's 64 entries are read before its compacted
+// entries, which land at or below the same indices, are written)
 // column stride: 260 floats shifts successive columns by 4 banks, so that lanes streaming different
 // columns at the same element offset (ds_read_b128) do not collide
 constexpr int kColStride = kWin * kWin + 4;
@@ -535,9 +540,11 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
     const float4 core = c->core[s];
     const int is_stable = c->tmin[s] == kIntMax ? 1 : 0;
     const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
-    float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2], *R = s_col[wv][3];
-    float *ONE = s_col[wv][4], *N0 = s_col[wv][5], *N1 = s_col[wv][6], *N2 = s_col[wv][7], *ld = s_col[wv][8];
-    int *lxy = reinterpret_cast<int *>(s_col[wv][9]);
+    float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2];
+    float *N0 = s_col[wv][3], *N1 = s_col[wv][4], *N2 = s_col[wv][5];
+    float *ld = P0, *R = N0, *ONE = N1;
+    int *lxy = reinterpret_cast<int *>(P1);
+    double *solver = reinterpret_cast<double *>(N2); // [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
 
     // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
     int n = 0;
@@ -619,22 +626,22 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
                 N0[pos] = nx; N1[pos] = ny; N2[pos] = nz;
                 float px, py, pz;
                 back_project(K, (float)x, (float)y, d, px, py, pz);
-                P0[pos] = px; P1[pos] = py; P2[pos] = pz; ONE[pos] = 1.0f;
+                P0[pos] = px; P1[pos] = py; P2[pos] = pz;
             }
             m_in += __popcll(m);
         }
         // pad every column the ordered sums stream to a multiple of 8 with +0.0f (see ordered_sum)
+        wave_lds_sync();
         pad_column(P0, m_in, lane); pad_column(P1, m_in, lane); pad_column(P2, m_in, lane);
-        pad_column(R, m_in, lane); pad_column(ONE, m_in, lane);
         pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
         wave_lds_sync();
         stamp(c, 3, s, 2, lane);
         if (!((double)((float)m_in / (float)n) < 0.8)) { // FF.cpp:862
             // sequential fp32 sums, FF.cpp:852-857 and 111-116
-            float sums[6];
-            ordered_sum6(N0, N1, N2, P0, P1, P2, m_in, sums);
-            float nx = sums[0], ny = sums[1], nz = sums[2], nb = 0;
-            float mx = sums[3], my = sums[4], mz = sums[5];
+            // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
+            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in);
+            float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2), nb = 0;
+            float mx = __shfl(part, 3), my = __shfl(part, 4), mz = __shfl(part, 5);
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
             nx = nx / len; ny = ny / len; nz = nz / len;
             mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
@@ -647,8 +654,20 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
                 if (i < m_in) {
                     q0[k] = P0[i] - mx; q1[k] = P1[i] - my; q2[k] = P2[i] - mz;
                     P0[i] = q0[k]; P1[i] = q1[k]; P2[i] = q2[k];
+                    ONE[i] = 1.0f; // the normal columns are dead from here on
                 }
             }
+            pad_column(ONE, m_in, lane);
+            pad_column(R, m_in, lane);
+            // per-lane rows of the tabled 4x4 inverse (dsm_math.h, kInv4)
+            int d2[4] = {0, 0, 0, 0}, oe[7] = {0, 0, 0, 0, 0, 0, 1};
+            if (lane < 12)
+#pragma unroll
+                for (int q = 0; q < 4; q++) d2[q] = kInv4.det2[lane][q];
+            if (lane < 16)
+#pragma unroll
+                for (int q = 0; q < 7; q++) oe[q] = kInv4.out[lane][q];
+            double *SA = solver, *SD = solver + 16, *SO = solver + 28, *SJ = solver + 44, *SU = solver + 48;
             stamp(c, 3, s, 3, lane);
             // operand columns of this lane's accumulator
             const bool is_j = lane >= 16;
@@ -674,12 +693,29 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
                 wave_lds_sync();
                 const double acc = gn_ordered_sum(xc, yc, m_in, noncore, upper, lower, is_j, hr);
                 wave_lds_sync();
-                double H[16], J[4];
+                // damped solve, FF.cpp:172-180: one lane per 2x2 determinant, per adjugate entry, per row
+                if (lane < 16) SA[lane] = (lane % 5 == 0) ? acc + 5 : acc; // +5 on the diagonal
+                else if (lane < 20) SJ[lane - 16] = acc;
+                wave_lds_sync();
+                if (lane < 12) SD[lane] = SA[d2[0]] * SA[d2[1]] - SA[d2[2]] * SA[d2[3]];
+                wave_lds_sync();
+                double Dv[12];
 #pragma unroll
-                for (int e = 0; e < 16; e++) H[e] = read_lane_f64(acc, e); // H[col*4+row]: a = row, b = col
-#pragma unroll
-                for (int e = 0; e < 4; e++) J[e] = read_lane_f64(acc, 16 + e);
-                gn_step(H, J, nx, ny, nz, nb);
+                for (int t = 0; t < 12; t++) Dv[t] = SD[t];
+                const double inv_det = 1.0 / inv4_det(Dv);
+                if (lane < 16) {
+                    const double g = (double)oe[6];
+                    const double t1 = g * (SA[oe[0]] * SD[oe[1]]), t2 = g * (SA[oe[2]] * SD[oe[3]]), t3 = g * (SA[oe[4]] * SD[oe[5]]);
+                    SO[lane] = ((t1 - t2) + t3) * inv_det;
+                }
+                wave_lds_sync();
+                if (lane < 4) SU[lane] = ((SO[lane] * SJ[0] + SO[4 + lane] * SJ[1]) + SO[8 + lane] * SJ[2]) + SO[12 + lane] * SJ[3];
+                wave_lds_sync();
+                nx = (float)((double)nx - SU[0]);
+                ny = (float)((double)ny - SU[1]);
+                nz = (float)((double)nz - SU[2]);
+                nb = (float)((double)nb - SU[3]);
+                wave_lds_sync();
             }
             stamp(c, 3, s, 4, lane);
             plane_finish(nx, ny, nz, nb, mx, my, mz);

@@ -167,6 +167,61 @@ template <typename T> DSM_HD void inverse4(const T *a, T *o) {
     o[15] = (a[2] * s3 - a[6] * s1 + a[10] * s0) * id;
 }
 
+// The same inverse as data: 12 2x2 determinants D[t] = a[da[t][0]]*a[da[t][1]] - a[da[t][2]]*a[da[t][3]]
+// (D[0..5] = s0..s5, D[6..11] = c0..c5), the determinant as a left-to-right chain over kDetTerms, and
+// 16 adjugate entries  o[k] = ((g*(a[x1]*D[d1]) - g*(a[x2]*D[d2])) + g*(a[x3]*D[d3])) * (1/det), g = +-1
+// (negating a product is exact, so this is inverse4 bit for bit).  The HIP kernel evaluates the table
+// with one lane per determinant / entry; inverse4_tabled is the serial form used to test the table.
+struct Inv4Tables {
+    signed char det2[12][4];
+    signed char det_terms[6][3];  // s index, c index (into D), sign
+    signed char out[16][7];       // x1 d1 x2 d2 x3 d3 leading sign
+};
+constexpr Inv4Tables kInv4 = {
+    {{0, 5, 1, 4}, {0, 9, 1, 8}, {0, 13, 1, 12}, {4, 9, 5, 8}, {4, 13, 5, 12}, {8, 13, 9, 12},
+     {2, 7, 3, 6}, {2, 11, 3, 10}, {2, 15, 3, 14}, {6, 11, 7, 10}, {6, 15, 7, 14}, {10, 15, 11, 14}},
+    {{0, 11, 1}, {1, 10, -1}, {2, 9, 1}, {3, 8, 1}, {4, 7, -1}, {5, 6, 1}},
+    {{5, 11, 9, 10, 13, 9, 1},   // o[0]  =  a5*c5 - a9*c4 + a13*c3
+     {1, 11, 9, 8, 13, 7, -1},   // o[1]  = -a1*c5 + a9*c2 - a13*c1
+     {1, 10, 5, 8, 13, 6, 1},    // o[2]  =  a1*c4 - a5*c2 + a13*c0
+     {1, 9, 5, 7, 9, 6, -1},     // o[3]  = -a1*c3 + a5*c1 - a9*c0
+     {4, 11, 8, 10, 12, 9, -1},  // o[4]  = -a4*c5 + a8*c4 - a12*c3
+     {0, 11, 8, 8, 12, 7, 1},    // o[5]  =  a0*c5 - a8*c2 + a12*c1
+     {0, 10, 4, 8, 12, 6, -1},   // o[6]  = -a0*c4 + a4*c2 - a12*c0
+     {0, 9, 4, 7, 8, 6, 1},      // o[7]  =  a0*c3 - a4*c1 + a8*c0
+     {7, 5, 11, 4, 15, 3, 1},    // o[8]  =  a7*s5 - a11*s4 + a15*s3
+     {3, 5, 11, 2, 15, 1, -1},   // o[9]  = -a3*s5 + a11*s2 - a15*s1
+     {3, 4, 7, 2, 15, 0, 1},     // o[10] =  a3*s4 - a7*s2 + a15*s0
+     {3, 3, 7, 1, 11, 0, -1},    // o[11] = -a3*s3 + a7*s1 - a11*s0
+     {6, 5, 10, 4, 14, 3, -1},   // o[12] = -a6*s5 + a10*s4 - a14*s3
+     {2, 5, 10, 2, 14, 1, 1},    // o[13] =  a2*s5 - a10*s2 + a14*s1
+     {2, 4, 6, 2, 14, 0, -1},    // o[14] = -a2*s4 + a6*s2 - a14*s0
+     {2, 3, 6, 1, 10, 0, 1}},    // o[15] =  a2*s3 - a6*s1 + a10*s0
+};
+template <typename T> DSM_HD T inv4_det2(const T *a, int t) {
+    return a[kInv4.det2[t][0]] * a[kInv4.det2[t][1]] - a[kInv4.det2[t][2]] * a[kInv4.det2[t][3]];
+}
+template <typename T> DSM_HD T inv4_det(const T *D) {
+    T det = D[kInv4.det_terms[0][0]] * D[kInv4.det_terms[0][1]];
+    for (int i = 1; i < 6; i++) {
+        const T prod = D[kInv4.det_terms[i][0]] * D[kInv4.det_terms[i][1]];
+        det = kInv4.det_terms[i][2] > 0 ? det + prod : det - prod;
+    }
+    return det;
+}
+template <typename T> DSM_HD T inv4_entry(const T *a, const T *D, T inv_det, int k) {
+    const signed char *e = kInv4.out[k];
+    const T g = (T)e[6];
+    const T t1 = g * (a[e[0]] * D[e[1]]), t2 = g * (a[e[2]] * D[e[3]]), t3 = g * (a[e[4]] * D[e[5]]);
+    return ((t1 - t2) + t3) * inv_det;
+}
+template <typename T> DSM_HD void inverse4_tabled(const T *a, T *o) {
+    T D[12];
+    for (int t = 0; t < 12; t++) D[t] = inv4_det2(a, t);
+    const T id = (T)1 / inv4_det(D);
+    for (int k = 0; k < 16; k++) o[k] = inv4_entry(a, D, id, k);
+}
+
 // One Gauss-Newton accumulator of get_huber_norm (FF.cpp:129-170).  The 16 Hessian entries and
 // the 4 Jacobian entries are independent sequential double sums; with the homogeneous point
 // p = (p0,p1,p2,1) they are  H(a,b) += (double)(2*p_a*p_b)  and  J(a) += (double)(2*r*p_a)  in

@@ -334,5 +334,7 @@ int emu_fuse_map(void *p, int ref_idx, const uint8_t *img, size_t img_step, cons
 void emu_get_labels(void *p, int32_t *out) { Emu &e = *(Emu *)p; memcpy(out, e.label.data(), sizeof(int32_t) * e.label.size()); }
 void emu_get_seeds(void *p, dsm_seed *out) { Emu &e = *(Emu *)p; memcpy(out, e.seeds.data(), sizeof(dsm_seed) * e.seeds.size()); }
 int emu_compact(dsm_surfel *local, int n, const dsm_surfel *fresh, int k) { return compact(local, n, fresh, k); }
+// table-driven inverse (the form the HIP kernel evaluates lane-parallel) vs the closed form
+void emu_inverse4d(const double *a, double *closed, double *tabled) { inverse4<double>(a, closed); inverse4_tabled<double>(a, tabled); }
 
 } // extern "C"

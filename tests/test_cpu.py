@@ -184,6 +184,22 @@ def test_parallel_compaction_bruteforce(ob, hostemu_lib):
         assert (b["update_times"][:n_b] != 0).all()
 
 
+def test_tabled_inverse_is_the_closed_form(hostemu_lib):
+    """The index/sign table the kernel evaluates with one lane per cofactor == inverse4, bit for bit."""
+    emu = C.CDLL(hostemu_lib)
+    emu.emu_inverse4d.argtypes = [C.c_void_p] * 3
+    rng = np.random.default_rng(9)
+    for trial in range(2000):
+        a = rng.normal(size=16) * 10.0 ** rng.integers(-3, 4)
+        if trial % 4 == 0:  # symmetric positive definite, like the damped Gauss-Newton Hessian
+            m = rng.normal(size=(4, 6))
+            a = (m @ m.T + 5 * np.eye(4)).ravel()
+        a = np.ascontiguousarray(a, np.float64)
+        x, y = np.zeros(16), np.zeros(16)
+        emu.emu_inverse4d(a.ctypes.data, x.ctypes.data, y.ctypes.data)
+        assert x.tobytes() == y.tobytes(), trial
+
+
 def test_stable_skip_fixed_point_bruteforce():
     """The tmin fixed point of k_assign/k_resolve/k_apply vs the reference's sequential scan
     (FF.cpp:400,445,450) on random (old label, pick, stable) instances."""
