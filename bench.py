@@ -100,6 +100,7 @@ def main():
                     help="host threads enqueueing graph replays (each drives streams/threads handles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -245,6 +246,21 @@ def main():
         ksum = sum(per.values()) * 1e-6
         b_alg_t = 9 * n + 60 * n_seed + 88 * mt + 44 * k_avg
         out["kernel_time_weighted_hbm_frac"] = round(b_alg_t / ksum / 1e9 / HBM_PEAK_GBS, 5)
+        ff.close()
+
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # the synchronous drop-in call (host buffers in and out over PCIe every frame), for DESIGN.md;
+        # never the headline value
+        ff = api.FusionFunctions.from_camera(cam, device=device, surfel_capacity=1 << 21)
+        local = np.zeros(0, api.SURFEL_DTYPE)
+        for t in range(40):
+            local, _ = ff.fuse_map(t // 5, rendered[t % period][0], rendered[t % period][1], scene.pose(t), local)
+        t_d = time.perf_counter()
+        for t in range(40, 70):
+            local, _ = ff.fuse_map(t // 5, rendered[t % period][0], rendered[t % period][1], scene.pose(t), local)
+        out["dropin_pcie_inclusive"] = {"value": round(30 / (time.perf_counter() - t_d), 1), "unit": "frames/s",
+                                        "map_surfels": int(len(local)),
+                                        "note": "dsm_fuse_map with host buffers: frame H2D + map H2D/D2H + sync per frame"}
         ff.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

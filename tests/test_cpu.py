@@ -315,3 +315,28 @@ def test_merge_clouds_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+# ------------------------------------------------------------------ C++ facade
+def _build_facade_test(oracle_built):
+    from densesurfelmapping_amd import api, build
+    build.build_library()
+    out = os.path.join(ROOT, "tests", "_build", "facade_test")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    pkg = os.path.dirname(api.LIB_PATH)
+    subprocess.run(["g++", "-std=c++11", "-O1", os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-o", out,
+                    "-L" + pkg, "-ldsm_hip", "-L" + oracle_built, "-loracle_port",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath," + oracle_built, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def test_cpp_facade_links_and_refuses_without_gpu(oracle_built):
+    """include/dsm_fusion_functions.hpp compiles as C++11 with stand-in cv::Mat / Eigen types and links
+    against the C ABI; without a GPU it must report 'no device' (exit 77), never compute."""
+    import torch
+    exe = _build_facade_test(oracle_built)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 77, r.stdout + r.stderr

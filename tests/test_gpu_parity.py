@@ -241,3 +241,12 @@ def test_golden_fixture(mods):
             assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == want["labels_sha256"], f"{case['name']} frame {t}"
         ref_map = np.load(os.path.join(ROOT, "tests", "golden", case["final_map"]))
         assert not fields_equal(lg, ref_map.astype(api.SURFEL_DTYPE)), case["name"]
+
+
+def test_cpp_facade_parity(mods, oracle_built):
+    """The C++ facade with the reference's class/method names, driven like surfel_map.cpp:1066-1109."""
+    import subprocess
+    from test_cpu import _build_facade_test
+    exe = _build_facade_test(oracle_built)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
