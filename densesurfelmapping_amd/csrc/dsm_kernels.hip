@@ -62,54 +62,31 @@ __device__ __forceinline__ int load_coherent(const int32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Ordered fp32 sum a = (((0 + l[0]) + l[1]) + ...) of an LDS list: the loads are block-fetched 8 at a
-// time (two ds_read_b128) so that only the adds are loop-carried.  l is 16-byte aligned and padded
-// with +0.0f up to a multiple of 8 (a running sum that starts at +0.0f can never be -0.0f, so adding
+// Ordered fp32 sum a = (((0 + l[0]) + l[1]) + ...) of an LDS list: the loads are block-fetched 16 at a
+// time (four ds_read_b128) so that only the adds are loop-carried.  l is 16-byte aligned and padded
+// with +0.0f up to a multiple of kBlk (a running sum that starts at +0.0f can never be -0.0f, so adding
 // +0.0f is the identity, bit for bit).
+constexpr int kBlk = 16;
+struct Blk16 {
+    float e[16];
+};
+__device__ __forceinline__ Blk16 load_blk(const float *l) {
+    const float4 a = *reinterpret_cast<const float4 *>(l), b = *reinterpret_cast<const float4 *>(l + 4);
+    const float4 c = *reinterpret_cast<const float4 *>(l + 8), d = *reinterpret_cast<const float4 *>(l + 12);
+    return Blk16{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w}};
+}
 __device__ __forceinline__ float ordered_sum(const float *l, int n) {
     float a = 0.0f;
-    for (int i = 0; i < n; i += 8) {
-        const float4 u = *reinterpret_cast<const float4 *>(l + i), v = *reinterpret_cast<const float4 *>(l + i + 4);
-        a += u.x; a += u.y; a += u.z; a += u.w;
-        a += v.x; a += v.y; a += v.z; a += v.w;
+    for (int i = 0; i < n; i += kBlk) {
+        const Blk16 v = load_blk(l + i);
+#pragma unroll
+        for (int q = 0; q < kBlk; q++) a += v.e[q];
     }
     return a;
 }
-// six independent ordered sums over columns of equal (padded) length, interleaved for ILP
-__device__ __forceinline__ void ordered_sum6(const float *c0, const float *c1, const float *c2, const float *c3,
-                                             const float *c4, const float *c5, int n, float out[6]) {
-    const float *col[6] = {c0, c1, c2, c3, c4, c5};
-    float a[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n; i += 8) {
-        float4 u[6], v[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            u[q] = *reinterpret_cast<const float4 *>(col[q] + i);
-            v[q] = *reinterpret_cast<const float4 *>(col[q] + i + 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += u[q].x;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += u[q].y;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += u[q].z;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += u[q].w;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += v[q].x;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += v[q].y;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += v[q].z;
-#pragma unroll
-        for (int q = 0; q < 6; q++) a[q] += v[q].w;
-    }
-#pragma unroll
-    for (int q = 0; q < 6; q++) out[q] = a[q];
-}
-// zero the padding slots [n, round_up(n, 8)) of a column
+// zero the padding slots [n, round_up(n, kBlk)) of a column
 __device__ __forceinline__ void pad_column(float *l, int n, int lane) {
-    if (lane < 8 && n + lane < ((n + 7) & ~7)) l[n + lane] = 0.0f;
+    if (lane < kBlk && n + lane < ((n + kBlk - 1) & ~(kBlk - 1))) l[n + lane] = 0.0f;
 }
 
 // debug: record the shader clock of phase `ph` of seed s in per-seed kernel `kid` (lane 0 only)
@@ -295,20 +272,18 @@ __device__ __forceinline__ float huber_ordered_sum(const float *lt, int nd, cons
     for (int k = 0; k < 4; k++) {
         const int lim = nd - k * 64 < 64 ? nd - k * 64 : 64;
         if (lim <= 0) break;
-        for (int j = 0; j < lim; j += 8) {
-            const float4 u = *reinterpret_cast<const float4 *>(lt + k * 64 + j);
-            const float4 v = *reinterpret_cast<const float4 *>(lt + k * 64 + j + 4);
-            const unsigned t8 = (unsigned)(tail[k] >> j) & 0xffu, p8 = (unsigned)(pos[k] >> j) & 0xffu;
-            if (t8 == 0) {
-                a += u.x; a += u.y; a += u.z; a += u.w;
-                a += v.x; a += v.y; a += v.z; a += v.w;
-            } else {
-                const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        for (int j = 0; j < lim; j += kBlk) {
+            const Blk16 v = load_blk(lt + k * 64 + j);
+            const unsigned t16 = (unsigned)(tail[k] >> j) & 0xffffu, p16 = (unsigned)(pos[k] >> j) & 0xffffu;
+            if (t16 == 0) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const float a_core = a + e[q];
-                    const float a_tail = (float)((double)a + (((p8 >> q) & 1u) ? hr : -1 * hr));
-                    a = ((t8 >> q) & 1u) ? a_tail : a_core;
+                for (int q = 0; q < kBlk; q++) a += v.e[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < kBlk; q++) {
+                    const float a_core = a + v.e[q];
+                    const float a_tail = (float)((double)a + (((p16 >> q) & 1u) ? hr : -1 * hr));
+                    a = ((t16 >> q) & 1u) ? a_tail : a_core;
                 }
             }
         }
@@ -501,20 +476,18 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
     for (int k = 0; k < 4; k++) {
         const int lim = m - k * 64 < 64 ? m - k * 64 : 64;
         if (lim <= 0) break;
-        for (int j = 0; j < lim; j += 8) {
+        for (int j = 0; j < lim; j += 8) { // 8 at a time here: two operand columns, register budget
             const int b = k * 64 + j;
             const float4 xa = *reinterpret_cast<const float4 *>(xc + b), xb = *reinterpret_cast<const float4 *>(xc + b + 4);
             const float4 ya = *reinterpret_cast<const float4 *>(yc + b), yb = *reinterpret_cast<const float4 *>(yc + b + 4);
+            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
             const unsigned n8 = (unsigned)(noncore[k] >> j) & 0xffu;
             if (n8 == 0) {
-                acc += (double)(2 * xa.x * ya.x); acc += (double)(2 * xa.y * ya.y);
-                acc += (double)(2 * xa.z * ya.z); acc += (double)(2 * xa.w * ya.w);
-                acc += (double)(2 * xb.x * yb.x); acc += (double)(2 * xb.y * yb.y);
-                acc += (double)(2 * xb.z * yb.z); acc += (double)(2 * xb.w * yb.w);
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += (double)(2 * xs[q] * ys[q]);
             } else {
                 const unsigned u8 = (unsigned)(upper[k] >> j) & 0xffu, l8 = (unsigned)(lower[k] >> j) & 0xffu;
-                const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int cls = !((n8 >> q) & 1u) ? 0 : ((u8 >> q) & 1u) ? 1 : ((l8 >> q) & 1u) ? 2 : 3;

@@ -27,6 +27,17 @@ struct Intrinsics {
     float fx, fy, cx, cy;
 };
 
+// x / 100.0, correctly rounded, in three operations instead of a full fp64 divide expansion:
+// q0 = RN(x*r), e = x - 100*q0 (exact in one FMA), q = RN(q0 + e*r) with r = RN(1/100) is the
+// correctly rounded quotient (Markstein's theorem; 100 = 1.5625*2^6 has no all-ones significand).
+// Checked against x/100.0 on 3e8 floats spanning all exponents (tests/test_cpu.py runs a sample).
+DSM_HD double div_by_100(double x) {
+    const double r = 1.0 / 100.0;
+    const double q0 = x * r;
+    const double e = __builtin_fma(-100.0, q0, x);
+    return __builtin_fma(e, r, q0);
+}
+
 // ---------------------------------------------------------------- SLIC cost, FF.cpp:364-387
 // Seed side: x, y, mean intensity, and the double 1.0/mean_depth (valid iff has_depth).
 // Returns whether the depth term applied.
@@ -37,7 +48,7 @@ DSM_HD bool pixel_cost(float sx, float sy, float si, bool seed_has_depth, double
     float cost = 0.0f;
     cost += dist / (float)((kCell / 2) * (kCell / 2));
     float di = si - pix_i;
-    cost = (float)((double)cost + (double)(di * di) / 100.0); // FF.cpp:376
+    cost = (float)((double)cost + div_by_100((double)(di * di))); // FF.cpp:376: (double)(di*di) / 100.0
     no_d = cost;
     with_d = cost;
     if (seed_has_depth && pix_invd > 0) {
@@ -49,9 +60,11 @@ DSM_HD bool pixel_cost(float sx, float sy, float si, bool seed_has_depth, double
 }
 
 // inverse depth of a pixel, FF.cpp:404-405
+// (float)(1.0 / (double)d): rounding a quotient of two 24-bit values first to 53 >= 2*24+2 bits and then
+// to 24 bits equals rounding it once (Figueroa), so the correctly rounded fp32 divide gives the same bits.
 DSM_HD float pixel_inv_depth(float d) {
     float invd = 0.0f;
-    if ((double)d > 0.01) invd = (float)(1.0 / (double)d);
+    if ((double)d > 0.01) invd = 1.0f / d;
     return invd;
 }
 

@@ -334,6 +334,14 @@ int emu_fuse_map(void *p, int ref_idx, const uint8_t *img, size_t img_step, cons
 void emu_get_labels(void *p, int32_t *out) { Emu &e = *(Emu *)p; memcpy(out, e.label.data(), sizeof(int32_t) * e.label.size()); }
 void emu_get_seeds(void *p, dsm_seed *out) { Emu &e = *(Emu *)p; memcpy(out, e.seeds.data(), sizeof(dsm_seed) * e.seeds.size()); }
 int emu_compact(dsm_surfel *local, int n, const dsm_surfel *fresh, int k) { return compact(local, n, fresh, k); }
+int emu_div100_mismatches(const float *x, int n) {
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const double a = (double)x[i] / 100.0, b = div_by_100((double)x[i]);
+        bad += memcmp(&a, &b, 8) != 0;
+    }
+    return bad;
+}
 // table-driven inverse (the form the HIP kernel evaluates lane-parallel) vs the closed form
 void emu_inverse4d(const double *a, double *closed, double *tabled) { inverse4<double>(a, closed); inverse4_tabled<double>(a, tabled); }
 

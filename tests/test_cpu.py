@@ -200,6 +200,19 @@ def test_tabled_inverse_is_the_closed_form(hostemu_lib):
         assert x.tobytes() == y.tobytes(), trial
 
 
+def test_div_by_100_is_the_ieee_quotient(hostemu_lib):
+    """The 3-operation x/100.0 of dsm_math.h == the IEEE quotient on random floats of every exponent."""
+    emu = C.CDLL(hostemu_lib)
+    emu.emu_div100_mismatches.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(4)
+    bits = rng.integers(0, 2 ** 32, 4_000_000, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = np.abs(x[np.isfinite(x)])
+    x = np.concatenate([x, (rng.uniform(-255, 255, 2_000_000).astype(np.float32)) ** 2])
+    x = np.ascontiguousarray(x, np.float32)
+    assert emu.emu_div100_mismatches(x.ctypes.data, len(x)) == 0
+
+
 def test_stable_skip_fixed_point_bruteforce():
     """The tmin fixed point of k_assign/k_resolve/k_apply vs the reference's sequential scan
     (FF.cpp:400,445,450) on random (old label, pick, stable) instances."""
