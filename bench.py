@@ -55,6 +55,17 @@ def stage_alg_bytes(stage, cam, n_seed, m_avg, k_avg):
     return n_seed * 16
 
 
+def pmc_traffic(stage):
+    """HBM-side bytes per launch of `stage` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs, tools/gpu_pmc.sh; profiles/r01_pmc_traffic.json records
+    them with the calibration used).  None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get("kernels", {}).get(stage.rstrip("_012") if stage[-1].isdigit() else stage)
+    return rec["hbm_bytes_per_launch"] if rec else None
+
+
 def cpu_baseline(cam, scene, synth, budget_s=12.0):
     """The reference's own fusion_functions.cpp (oracle/_ref, real 10-thread schedule) if its prebuilt
     library is present, else our C restatement (1 thread), on a bounded sample of the same workload."""
@@ -234,12 +245,14 @@ def main():
         stages, nfr = ff.replay_timed(s[20:], r[20:], p[20:])
         m1 = ff.map_size()
         mt = (m0 + m1) / 2
-        per = {k: v[0] / max(v[1], 1) * 1e3 for k, v in stages.items()}  # us per launch
+        ovh = ff.event_overhead_ms * 1e3  # an empty event-to-event interval, subtracted from every stage
+        per = {k: max(v[0] / max(v[1], 1) * 1e3 - ovh, 0.0) for k, v in stages.items()}  # us per launch
         dom = max(per, key=per.get)
         alg = stage_alg_bytes(dom, cam, n_seed, mt, k_avg)
         achieved = alg / (per[dom] * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
+                           "event_overhead_us": round(ovh, 2),
                            "alg_bytes_per_launch": int(alg), "avg_launch_us": round(per[dom], 2)}
         out["kernel_us"] = {k: round(v, 2) for k, v in per.items()}
         out["frame_kernel_sum_us"] = round(sum(per.values()), 1)

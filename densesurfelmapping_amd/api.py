@@ -68,7 +68,7 @@ class _Config(C.Structure):
 class _StageTimes(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("name", C.c_char_p * DSM_MAX_STAGES),
                 ("ms", C.c_double * DSM_MAX_STAGES), ("launches", C.c_int64 * DSM_MAX_STAGES),
-                ("frames", C.c_int64)]
+                ("frames", C.c_int64), ("event_overhead_ms", C.c_double)]
 
 
 _vp = C.c_void_p
@@ -289,4 +289,5 @@ class FusionFunctions:
         st = _StageTimes()
         self._check(self._lib.dsm_replay_timed(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm),
                                                C.byref(st)))
+        self.event_overhead_ms = st.event_overhead_ms / max(st.frames, 1)
         return {st.name[i].decode(): (st.ms[i], st.launches[i]) for i in range(st.n_stages)}, st.frames

@@ -40,7 +40,7 @@ struct dsm_handle {
     int64_t frames_submitted = 0, frames_done = 0;
     int map_upper = 0; // host-side upper bound of the resident map size
     bool map_valid = false;
-    hipEvent_t ev[kNumStages + 1];
+    hipEvent_t ev[kNumStages + 2];
     bool have_events = false;
     std::string err;
 };
@@ -319,7 +319,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 64, hipHostMallocDefault));
     memset(h->h_scalars, 0, 64);
     CREATE_TRY(hipMemcpyAsync(h->d_ctx, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
-    for (int i = 0; i <= kNumStages; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
+    for (int i = 0; i <= kNumStages + 1; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
     h->have_events = true;
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -335,7 +335,7 @@ void dsm_destroy(dsm_handle *h) {
     for (int i = 0; i < 2; i++)
         if (h->graph[i]) (void)hipGraphExecDestroy(h->graph[i]);
     if (h->have_events)
-        for (int i = 0; i <= kNumStages; i++) (void)hipEventDestroy(h->ev[i]);
+        for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->h_params) (void)hipHostFree(h->h_params);
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
@@ -559,6 +559,9 @@ int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32
             out->ms[s] += (double)ms;
             out->launches[s] += 1;
         }
+        float cal = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&cal, h->ev[kNumStages], h->ev[kNumStages + 1]));
+        out->event_overhead_ms += (double)cal;
         out->frames += 1;
     }
     return DSM_OK;

@@ -94,6 +94,32 @@ __device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph
     if (c->stamps && lane == 0) c->stamps[((int64_t)kid * c->n_seed + s) * 8 + ph] = clock64();
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.
+// The per-seed kernels read overlapping 16x16 windows, so neighbouring seeds should share an L2:
+// XCD k works on the k-th vertical strip of the seed grid, top to bottom (vertical strips rather than
+// bands of rows, because rows differ a lot in cost -- sky rows are empty -- and strips do not).
+// A block is 4 consecutive seeds of one row; returns the seed of wave `wv`, or -1 outside the grid.
+//
+// Measured on MI355X at 1226x370 (profiles/r01_xcd_mapping.md): strips cut the fabric reads of
+// k_seed_planes from 7.4 MB to 2.7 MB per launch (FETCH_SIZE) but the kernel got *slower* (41.5 -> 48.5
+// us, and bands of rows 44.7 us) and 8-stream throughput fell 14.5k -> 13.1k frames/s: the path is bound by
+// dependent-operation latency, not by fabric bytes, and the plain round-robin order spreads the expensive
+// seeds best.  The plain order is therefore the default; -DDSM_XCD_STRIPS=1 selects the strips.
+#ifndef DSM_XCD_STRIPS
+#define DSM_XCD_STRIPS 0
+#endif
+__device__ __forceinline__ int strip_blocks_per_row(int gw) { return (((gw + 3) >> 2) + 7) >> 3; }
+__device__ __forceinline__ int seed_of_block(int b, int wv, int gw, int gh) {
+#if !DSM_XCD_STRIPS
+    const int s = b * 4 + wv;
+    return s < gw * gh ? s : -1;
+#endif
+    const int spr = strip_blocks_per_row(gw);
+    const int strip = b & 7, i = b >> 3;
+    const int gy = i / spr, gx = ((strip * spr + i % spr) << 2) + wv;
+    return (gx < gw && gy < gh) ? gy * gw + gx : -1;
+}
+
 __device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur; }
 __device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return c->cur_img; }
 __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur_dep; }
@@ -305,8 +331,8 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(cons
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = blockIdx.x * 4 + wv;
-    if (s >= c->n_seed) return;
+    const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
+    if (s < 0) return;
     stamp(c, sweep, s, 0, lane);
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
@@ -502,8 +528,8 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
 __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict__ c) {
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = blockIdx.x * 4 + wv;
-    if (s >= c->n_seed) return;
+    const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
+    if (s < 0) return;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
@@ -985,7 +1011,12 @@ hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_b
         stage++;                                                                        \
     } while (0)
     const int S = hc.n_seed;
-    const dim3 g_seed_thr((S + 255) / 256), g_seed_wave((S + 3) / 4);
+    const dim3 g_seed_thr((S + 255) / 256);
+#if DSM_XCD_STRIPS
+    const dim3 g_seed_wave(8 * ((((hc.gw + 3) / 4 + 7) / 8) * hc.gh)); // 8 strips x blocks per strip (seed_of_block)
+#else
+    const dim3 g_seed_wave((S + 3) / 4);
+#endif
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
@@ -1017,6 +1048,10 @@ hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_b
     DSM_MARK();
     hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1024), 0, st, d, with_compaction ? 1 : 0);
     DSM_MARK();
+    if (ev) { // empty interval: what a pair of event records costs by itself
+        err = hipEventRecord(ev[stage], st);
+        if (err != hipSuccess) return err;
+    }
 #undef DSM_MARK
     return hipGetLastError();
 }

@@ -160,6 +160,7 @@ typedef struct dsm_stage_times {
     double ms[DSM_MAX_STAGES];      /* accumulated kernel time per stage */
     int64_t launches[DSM_MAX_STAGES];
     int64_t frames;
+    double event_overhead_ms;       /* accumulated length of one empty event-to-event interval per frame */
 } dsm_stage_times;
 /* run the resident fuse for n frames eagerly with an event pair around every kernel and
  * accumulate per-stage durations */
