@@ -62,7 +62,8 @@ def pmc_traffic(stage):
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
-    rec = json.load(open(path)).get("kernels", {}).get(stage.rstrip("_012") if stage[-1].isdigit() else stage)
+    kernels = json.load(open(path)).get("kernels", {})
+    rec = kernels.get(stage) or kernels.get(stage.rstrip("012").rstrip("_"))
     return rec["hbm_bytes_per_launch"] if rec else None
 
 
