@@ -277,6 +277,32 @@ def main():
                                         "note": "dsm_fuse_map with host buffers: frame H2D + map H2D/D2H + sync per frame"}
         ff.close()
 
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # SURVEY.md §8(f) row 1, BASELINE configs[4] size: loop-closure deformation of a 2 M-surfel resident map
+        # (surfel_map.cpp:750-789), the one purely HBM-bound stage: 88 B per surfel
+        n_w = 2_000_000
+        wm = np.zeros(n_w, api.SURFEL_DTYPE)
+        wm["px"] = np.arange(n_w, dtype=np.float32) * 1e-3
+        wm["nz"] = 1.0
+        wm["update_times"] = 3
+        ff = api.FusionFunctions.from_camera(synth.TINY, device=device, surfel_capacity=n_w + 64)
+        ff.map_upload(wm)
+        wp = np.eye(4, dtype=np.float32)
+        wp[:3, 3] = (0.01, -0.02, 0.005)
+        for _ in range(5):
+            ff.map_warp(wp)
+        ff.synchronize()
+        t_w = time.perf_counter()
+        for _ in range(100):
+            ff.map_warp(wp)
+        ff.synchronize()
+        dt_w = (time.perf_counter() - t_w) / 100
+        out["map_warp_2M"] = {"us_per_call": round(dt_w * 1e6, 1), "achieved_GBps": round(n_w * 88 / dt_w / 1e9, 1),
+                              "hbm_frac": round(n_w * 88 / dt_w / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "dsm_map_warp incl. its per-call host sync; 176 MB working set sits in the 256 MB Infinity Cache "
+                                      "(kernel alone 26.8 us in profiles/r01_kernel_trace_warp_2M.md); 8 M surfels (704 MB): 5.1 TB/s"}
+        ff.close()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cam, synth.Scene(seed=12345, frames_per_period=period), synth)
 

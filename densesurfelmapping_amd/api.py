@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "dsm_abi_version", "dsm_config_init", "dsm_create", "dsm_destroy", "dsm_last_error",
     "dsm_fuse_initialize_map", "dsm_fuse_map",
     "dsm_map_upload", "dsm_map_size", "dsm_map_download", "dsm_map_copy_to_device",
+    "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
     "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps",
@@ -98,6 +99,10 @@ def load_library():
     lib.dsm_map_size.argtypes = [_vp, _vp]
     lib.dsm_map_download.argtypes = [_vp, _vp, C.c_int32, _vp]
     lib.dsm_map_copy_to_device.argtypes = [_vp, _vp, C.c_int32, _vp]
+    lib.dsm_map_warp.argtypes = [_vp, _vp]
+    lib.dsm_warp_grouped_device.argtypes = [_vp, _vp, C.c_int32, _vp, _vp]
+    lib.dsm_map_extract.argtypes = [_vp, C.c_int32, _vp, C.c_int32, _vp]
+    lib.dsm_map_append.argtypes = [_vp, _vp, C.c_int32]
     lib.dsm_frame_upload.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
     lib.dsm_frame_upload_device.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
     lib.dsm_fuse_frame_resident.argtypes = [_vp, C.c_int, C.c_int, _vp]
@@ -230,6 +235,29 @@ class FusionFunctions:
         n = C.c_int32(0)
         self._check(self._lib.dsm_map_copy_to_device(self._h, _vp(dst_ptr), cap, C.byref(n)))
         return n.value
+
+    # ---- map maintenance between frames (surfel_map.cpp:681-824, 1456-1595) -----------------
+    def map_warp(self, warp):
+        """SurfelMap::warp_active_surfels_cpu_kernel: warp = (loop_pose * cam_pose^-1) as 4x4 float."""
+        w = pose_to_colmajor(warp)
+        self._check(self._lib.dsm_map_warp(self._h, _ptr(w)))
+
+    def warp_grouped_device(self, surfels_ptr, offsets, mats):
+        """SurfelMap::warp_inactive_surfels_cpu_kernel on device memory: mats [g,4,4], offsets [g+1]."""
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        mats_cm = np.ascontiguousarray(np.asarray(mats, np.float32).transpose(0, 2, 1)).reshape(-1, 16)
+        self._check(self._lib.dsm_warp_grouped_device(self._h, _vp(surfels_ptr), len(offsets) - 1, _ptr(offsets), _ptr(mats_cm)))
+
+    def map_extract(self, key) -> np.ndarray:
+        """move_add_surfels removal: live surfels with last_update == key, in order; their slots are deleted."""
+        out = np.zeros(max(self.map_size(), 1), SURFEL_DTYPE)
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_map_extract(self._h, key, _ptr(out), len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def map_append(self, surfels):
+        a = np.ascontiguousarray(surfels, SURFEL_DTYPE)
+        self._check(self._lib.dsm_map_append(self._h, _ptr(a), len(a)))
 
     def frame_upload(self, slot, image, depth):
         image, depth = self._frame_args(image, depth)

@@ -35,6 +35,7 @@ struct dsm_handle {
     FrameParams *h_params = nullptr; // pinned staging ring
     int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
     FrameParams *d_params = nullptr;
+    float *d_warp = nullptr; // 16 floats
     hipGraphExec_t graph[2] = {nullptr, nullptr}; // [with_compaction]
     int graph_fuse_bound = 0;
     int64_t frames_submitted = 0, frames_done = 0;
@@ -314,10 +315,11 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         if (e[0] == '1') CREATE_TRY(dev_alloc(h, &c.stamps, (size_t)4 * c.n_seed * 8));
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
+    CREATE_TRY(dev_alloc(h, &h->d_warp, 16));
     CREATE_TRY(dev_alloc(h, &h->d_ctx, 1));
     CREATE_TRY(hipHostMalloc((void **)&h->h_params, sizeof(FrameParams) * kParamRing, hipHostMallocDefault));
-    CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 64, hipHostMallocDefault));
-    memset(h->h_scalars, 0, 64);
+    CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 256, hipHostMallocDefault));
+    memset(h->h_scalars, 0, 256);
     CREATE_TRY(hipMemcpyAsync(h->d_ctx, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
     for (int i = 0; i <= kNumStages + 1; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
     h->have_events = true;
@@ -435,6 +437,89 @@ int dsm_map_copy_to_device(dsm_handle *h, void *dst_device, int32_t cap, int32_t
     if (m > cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap);
     if (m && !dst_device) return fail(h, DSM_E_INVALID, "null output");
     if (m) HIP_TRY(h, hipMemcpy(dst_device, h->hc.local, (size_t)m * sizeof(dsm_surfel), hipMemcpyDeviceToDevice));
+    return DSM_OK;
+}
+
+// ------------------------------------------------------------------ map maintenance
+
+int dsm_map_warp(dsm_handle *h, const float *warp16) {
+    if (!h) return DSM_E_INVALID;
+    if (!warp16) return fail(h, DSM_E_INVALID, "null matrix");
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    // the matrix travels through the params ring's pinned staging: wait until the slot is free
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->frames_done = h->frames_submitted;
+    memcpy(h->h_scalars + 16, warp16, 64);
+    HIP_TRY(h, hipMemcpyAsync(h->d_warp, h->h_scalars + 16, 64, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_warp(h->hc.local, h->hc.n_local, 0, h->d_warp, nullptr, 0, h->map_upper, h->stream);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "warp launch: %s", hipGetErrorString(e));
+    return DSM_OK;
+}
+
+int dsm_warp_grouped_device(dsm_handle *h, void *surfels_device, int32_t n_groups, const int32_t *offsets,
+                            const float *mats16) {
+    if (!h) return DSM_E_INVALID;
+    if (n_groups < 0 || (n_groups > 0 && (!surfels_device || !offsets || !mats16))) return fail(h, DSM_E_INVALID, "null/negative argument");
+    if (n_groups == 0) return DSM_OK;
+    for (int g = 0; g < n_groups; g++)
+        if (offsets[g] > offsets[g + 1] || offsets[0] != 0) return fail(h, DSM_E_INVALID, "offsets must start at 0 and ascend");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    float *d_m = nullptr;
+    int32_t *d_o = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d_m, sizeof(float) * 16 * (size_t)n_groups));
+    hipError_t e = hipMalloc((void **)&d_o, sizeof(int32_t) * ((size_t)n_groups + 1));
+    if (e != hipSuccess) { (void)hipFree(d_m); return fail(h, DSM_E_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpy(d_m, mats16, sizeof(float) * 16 * (size_t)n_groups, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_o, offsets, sizeof(int32_t) * ((size_t)n_groups + 1), hipMemcpyHostToDevice);
+    const int n = offsets[n_groups];
+    if (e == hipSuccess) e = launch_warp((dsm_surfel *)surfels_device, nullptr, n, d_m, d_o, n_groups, n, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_m);
+    (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "grouped warp: %s", hipGetErrorString(e));
+    return DSM_OK;
+}
+
+int dsm_map_extract(dsm_handle *h, int32_t key, dsm_surfel *out, int32_t cap, int32_t *n) {
+    if (!h || !n || cap < 0 || (cap > 0 && !out)) return DSM_E_INVALID;
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    // staged in `fresh`'s neighbour: the holes array doubles as the index list, the copy goes to a scratch buffer
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    dsm_surfel *d_out = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d_out, sizeof(dsm_surfel) * (size_t)(m > 0 ? m : 1)));
+    hipError_t e = launch_extract(h->d_ctx, key, d_out, m, m, h->stream);
+    int32_t k = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h->h_scalars[3], h->hc.n_holes, 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) {
+        k = h->h_scalars[3];
+        if (k > cap) { (void)hipFree(d_out); *n = k; return fail(h, DSM_E_CAPACITY, "%d surfels of keyframe %d exceed cap %d (map left with them deleted)", k, key, cap); }
+        if (k) e = hipMemcpy(out, d_out, sizeof(dsm_surfel) * (size_t)k, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "extract: %s", hipGetErrorString(e));
+    *n = k;
+    return DSM_OK;
+}
+
+int dsm_map_append(dsm_handle *h, const dsm_surfel *surfels, int32_t n) {
+    if (!h || n < 0 || (n > 0 && !surfels)) return DSM_E_INVALID;
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    if (m + n > h->hc.cap) return fail(h, DSM_E_CAPACITY, "%d + %d surfels exceed the handle's capacity %d", m, n, h->hc.cap);
+    if (n) HIP_TRY(h, hipMemcpy(h->hc.local + m, surfels, sizeof(dsm_surfel) * (size_t)n, hipMemcpyHostToDevice));
+    hipError_t e = launch_append_count(h->d_ctx, n, h->stream);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "append: %s", hipGetErrorString(e));
+    h->map_upper = m + n;
     return DSM_OK;
 }
 

@@ -85,4 +85,9 @@ extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx *d_ctx, const DeviceCtx &h_ctx, int map_upper_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev);
 
+hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
+                       const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st);
+hipError_t launch_extract(const DeviceCtx *d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st);
+hipError_t launch_append_count(const DeviceCtx *d, int n, hipStream_t st);
+
 } // namespace dsm

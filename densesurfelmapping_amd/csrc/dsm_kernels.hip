@@ -982,6 +982,117 @@ __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------ map deformation
+// SM.cpp:681-824.  Streaming 3x4 transform of position and normal of every surfel; the one stage of the
+// product that is purely HBM-bound (88 B per surfel: the 44-byte AoS record is read and rewritten whole).
+// A block moves 256 records = 704 16-byte vectors through LDS with fully coalesced loads and stores; a
+// lane then owns one record at stride 11 dwords (odd: conflict-free).  group_offsets == nullptr: one
+// matrix for all (the reference's active-map case); otherwise record i uses the matrix of its group.
+__global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, const int32_t *__restrict__ n_ptr,
+                                              int32_t n_fixed, const float *__restrict__ mats,
+                                              const int32_t *__restrict__ group_offsets, int32_t n_groups) {
+    __shared__ __attribute__((aligned(16))) float s_rec[256 * 11];
+    const int n = n_ptr ? n_ptr[0] : n_fixed;
+    const int tid = threadIdx.x;
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const int cnt = n - base < 256 ? n - base : 256;
+        const int n_vec = (cnt * 11 + 3) >> 2; // 44-byte records: a block of 256 starts 16-byte aligned
+        const float4 *src = reinterpret_cast<const float4 *>(surfels + base);
+        float4 *dst = reinterpret_cast<float4 *>(surfels + base);
+        float4 *lds4 = reinterpret_cast<float4 *>(s_rec);
+        const bool whole = cnt == 256 || ((cnt * 11) & 3) == 0;
+        for (int v = tid; v < n_vec; v += 256) {
+            if (whole || v < n_vec - 1) lds4[v] = src[v];
+            else { // ragged last vector of the array: dword by dword
+                const float *s1 = reinterpret_cast<const float *>(surfels + base);
+                for (int e = v * 4; e < cnt * 11; e++) s_rec[e] = s1[e];
+            }
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            const float *m = mats;
+            if (group_offsets) {
+                int lo = 0, hi = n_groups; // last g with offsets[g] <= i
+                const int i = base + tid;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (group_offsets[mid] <= i) lo = mid; else hi = mid;
+                }
+                m = mats + 16 * lo;
+            }
+            float *r = s_rec + tid * 11;
+            const float p[3] = {r[0], r[1], r[2]}, v[3] = {r[3], r[4], r[5]};
+            float o[3], w[3];
+            xform_point(m, p, o);
+            xform_dir(m, v, w);
+            r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+            r[3] = w[0]; r[4] = w[1]; r[5] = w[2];
+        }
+        __syncthreads();
+        for (int v = tid; v < n_vec; v += 256) {
+            if (whole || v < n_vec - 1) dst[v] = lds4[v];
+            else {
+                float *d1 = reinterpret_cast<float *>(surfels + base);
+                for (int e = v * 4; e < cnt * 11; e++) d1[e] = s_rec[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------ active-set maintenance
+// SM.cpp:1476-1497: bitmap of live surfels attached to keyframe `key` (reuses the hole bitmap arrays: they are
+// rebuilt by every frame), then the same one-workgroup scan, then an ordered copy-out that deletes the slots.
+__global__ __launch_bounds__(256) void k_mark_key(const DeviceCtx *__restrict__ c, int key) {
+    const int M = c->n_local[0];
+    const int n_wave = (M + 63) >> 6, lane = lane_id();
+    const int waves_total = (gridDim.x * 256) >> 6;
+    for (int wv = (blockIdx.x * 256 + threadIdx.x) >> 6; wv < n_wave; wv += waves_total) {
+        const int i = wv * 64 + lane;
+        bool hit = false;
+        if (i < M) hit = c->local[i].update_times > 0 && c->local[i].last_update == key;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) c->hole_mask[wv] = m;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_marks(const DeviceCtx *__restrict__ c) {
+    __shared__ int s_wave[17];
+    tail_hole_scan(c, s_wave); // wave_prefix, holes (= marked indices, ascending), n_holes
+}
+__global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx *__restrict__ c, dsm_surfel *__restrict__ out, int cap) {
+    const int k = c->n_holes[0];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < k && j < cap; j += gridDim.x * 256) {
+        const int i = c->holes[j];
+        out[j] = c->local[i];
+        c->local[i].update_times = 0;
+    }
+}
+__global__ void k_append(const DeviceCtx *__restrict__ c, int n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) c->n_local[0] = c->n_local[0] + n;
+}
+
+hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
+                       const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st) {
+    int blocks = (n_upper + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, d_offsets, n_groups);
+    return hipGetLastError();
+}
+hipError_t launch_extract(const DeviceCtx *d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st) {
+    int blocks = (n_upper + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_mark_key, dim3(blocks), dim3(256), 0, st, d, key);
+    hipLaunchKernelGGL(k_scan_marks, dim3(1), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(k_extract_marked, dim3(64), dim3(256), 0, st, d, out, cap);
+    return hipGetLastError();
+}
+hipError_t launch_append_count(const DeviceCtx *d, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_append, dim3(1), dim3(64), 0, st, d, n);
+    return hipGetLastError();
+}
+
 // Timed replays only: keep the GPU busy for `ticks` of the 100 MHz wall clock while the host enqueues
 // the whole frame, so that the events between kernels do not measure host launch latency.
 __global__ void k_delay(long long ticks) {

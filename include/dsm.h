@@ -126,6 +126,23 @@ int dsm_map_download(dsm_handle *h, dsm_surfel *out, int32_t cap, int32_t *n); /
  * tensor's data_ptr) for the multi-GPU merge; synchronises. */
 int dsm_map_copy_to_device(dsm_handle *h, void *dst_device, int32_t cap, int32_t *n);
 
+/* ---- map maintenance between frames (the data-parallel parts of surfel_map.cpp:681-824, 1456-1595) ---- */
+
+/* SurfelMap::warp_active_surfels_cpu_kernel (surfel_map.cpp:750-789): p' = M*(p,1), n' = M[0:3,0:3]*n for
+ * every resident surfel; warp16 = (loop_pose * cam_pose^-1).cast<float>(), column-major (surfel_map.cpp:808-813).
+ * Asynchronous on the handle's stream. */
+int dsm_map_warp(dsm_handle *h, const float *warp16);
+/* SurfelMap::warp_inactive_surfels_cpu_kernel (surfel_map.cpp:681-748) on caller-owned DEVICE memory: the
+ * attached surfels of n_groups keyframes stored back to back, group g = [offsets[g], offsets[g+1]) warped by
+ * mats16[16 g ..].  offsets (n_groups+1) and mats16 are host arrays.  Synchronises. */
+int dsm_warp_grouped_device(dsm_handle *h, void *surfels_device, int32_t n_groups, const int32_t *offsets,
+                            const float *mats16);
+/* move_add_surfels, removal half (surfel_map.cpp:1476-1497): copy the live resident surfels whose
+ * last_update == key to out[] in index order and mark their slots deleted.  Synchronises. */
+int dsm_map_extract(dsm_handle *h, int32_t key, dsm_surfel *out, int32_t cap, int32_t *n);
+/* move_add_surfels, insertion half (surfel_map.cpp:1583-1590): append to the resident map. */
+int dsm_map_append(dsm_handle *h, const dsm_surfel *surfels, int32_t n);
+
 int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
                      size_t depth_step);
 /* same, sources already in device memory */

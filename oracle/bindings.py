@@ -151,6 +151,27 @@ class _Base:
         self._call(name)
 
 
+def port_warp(surfels, warp):
+    """dsmo_warp on a copy of `surfels` (SURFEL_DTYPE); warp is a 4x4 row-major numpy matrix."""
+    lib = C.CDLL(os.path.join(HERE, "liboracle_port.so"))
+    lib.dsmo_warp.argtypes = [_vp, C.c_int, _vp]
+    a = np.ascontiguousarray(surfels, SURFEL_DTYPE).copy()
+    m = np.ascontiguousarray(np.asarray(warp, np.float32).T).ravel()
+    lib.dsmo_warp(_ptr(a), len(a), _ptr(m))
+    return a
+
+
+def port_extract_key(local, key):
+    """dsmo_extract_key: returns (local with the slots deleted, extracted surfels)."""
+    lib = C.CDLL(os.path.join(HERE, "liboracle_port.so"))
+    lib.dsmo_extract_key.argtypes = [_vp, C.c_int, C.c_int, _vp]
+    lib.dsmo_extract_key.restype = C.c_int
+    a = np.ascontiguousarray(local, SURFEL_DTYPE).copy()
+    out = np.zeros(max(len(a), 1), SURFEL_DTYPE)
+    k = lib.dsmo_extract_key(_ptr(a), len(a), key, _ptr(out))
+    return a, out[:k].copy()
+
+
 class RefOracle(_Base):
     prefix = "dsmref_"
 

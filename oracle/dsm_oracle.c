@@ -527,6 +527,28 @@ int dsmo_fuse_map(dsmo_ctx *c, int ref_idx, const uint8_t *img, size_t img_step,
     return rc;
 }
 
+/* SM.cpp:750-789 (active) and 712-733 (inactive): p' = M * (p,1), n' = M[0:3,0:3] * n */
+void dsmo_warp(dsmo_surfel *s, int n, const float *m) {
+    for (int i = 0; i < n; i++) {
+        float p[3] = {s[i].px, s[i].py, s[i].pz}, v[3] = {s[i].nx, s[i].ny, s[i].nz}, o[3], w[3];
+        xform_point(m, p, o);
+        xform_dir(m, v, w);
+        s[i].px = o[0]; s[i].py = o[1]; s[i].pz = o[2];
+        s[i].nx = w[0]; s[i].ny = w[1]; s[i].nz = w[2];
+    }
+}
+
+/* SM.cpp:1476-1497 */
+int dsmo_extract_key(dsmo_surfel *local, int n, int key, dsmo_surfel *out) {
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        if (local[i].update_times > 0 && local[i].last_update == key) {
+            out[k++] = local[i];
+            local[i].update_times = 0;
+        }
+    return k;
+}
+
 /* ------------------------------------------------------------------- taps */
 void dsmo_get_labels(dsmo_ctx *c, int32_t *out) { memcpy(out, c->label, sizeof(int32_t) * (size_t)c->w * c->h); }
 void dsmo_set_labels(dsmo_ctx *c, const int32_t *in) { memcpy(c->label, in, sizeof(int32_t) * (size_t)c->w * c->h); }

@@ -71,6 +71,14 @@ void dsmo_update_pixels(dsmo_ctx *c);
 void dsmo_update_seeds(dsmo_ctx *c);
 void dsmo_calculate_norms(dsmo_ctx *c);
 
+/* surfel_map.cpp:750-789 / 712-733: rigid warp of positions and normals by a column-major 4x4 float
+ * matrix (Eigen MatrixXf products; accumulation left to right as everywhere in the shims -- Eigen3 itself
+ * is absent, so this stays "parity unpinned" like the 4x4 inverse). */
+void dsmo_warp(dsmo_surfel *s, int n, const float *m16);
+/* surfel_map.cpp:1476-1497: move the live surfels whose last_update == key out of `local` (in index
+ * order) into `out`, marking their slots deleted (update_times = 0); returns how many. */
+int dsmo_extract_key(dsmo_surfel *local, int n, int key, dsmo_surfel *out);
+
 /* general 4x4 inverse (adjugate / determinant), column-major */
 void dsmo_inverse4f(const float *a, float *out);
 

@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def mods(oracle_built):
+    import torch
+    torch.cuda.init()  # torch's lazy HIP initialisation first: tests below hand torch device memory to the library
     from densesurfelmapping_amd import api, synth
     from oracle import bindings
     return api, synth, bindings
@@ -250,3 +252,93 @@ def test_cpp_facade_parity(mods, oracle_built):
     exe = _build_facade_test(oracle_built)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _random_rigid(rng, scale=0.05):
+    a = rng.normal(size=3) * scale
+    th = np.linalg.norm(a)
+    k = a / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    m = np.eye(4)
+    m[:3, :3] = R
+    m[:3, 3] = rng.normal(size=3) * 0.3
+    return m.astype(np.float32)
+
+
+def _fused_map(mods, n_frames=6):
+    api, synth, ob = mods
+    cam, scene = synth.VGA_DRIVE, synth.Scene(seed=31)
+    orc = ob.PortOracle(cam)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, n_frames):
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+    return cam, scene, orc, lo
+
+
+def test_map_warp_matches_oracle(mods):
+    """Loop-closure deformation of the resident (active) map, surfel_map.cpp:750-789."""
+    api, synth, ob = mods
+    cam, scene, orc, lo = _fused_map(mods)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
+    rng = np.random.default_rng(5)
+    for n in (len(lo), 1, 255, 256, 257, 1000):  # ragged tails of the 256-record blocks
+        sub = lo[:n]
+        warp = _random_rigid(rng)
+        ff.map_upload(sub.astype(api.SURFEL_DTYPE))
+        ff.map_warp(warp)
+        got = ff.map_download()
+        want = ob.port_warp(sub, warp).astype(api.SURFEL_DTYPE)
+        assert not fields_equal(got, want), n
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    ff.map_warp(np.eye(4, dtype=np.float32))
+    assert ff.map_size() == 0
+
+
+def test_warp_grouped_device_matches_oracle(mods):
+    """Per-keyframe deformation of detached surfels in caller-owned device memory, surfel_map.cpp:681-748."""
+    import torch
+    api, synth, ob = mods
+    cam, scene, orc, lo = _fused_map(mods)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1024)
+    rng = np.random.default_rng(6)
+    cuts = np.sort(rng.choice(np.arange(1, len(lo)), size=6, replace=False))
+    offsets = np.concatenate([[0], cuts, [cuts[-1]], [len(lo)]]).astype(np.int32)  # includes an empty group
+    mats = np.stack([_random_rigid(rng) for _ in range(len(offsets) - 1)])
+    dev = torch.from_numpy(lo.view(np.uint8).copy()).cuda()
+    ff.warp_grouped_device(dev.data_ptr(), offsets, mats)
+    got = dev.cpu().numpy().view(api.SURFEL_DTYPE)
+    want = lo.copy()
+    for g in range(len(offsets) - 1):
+        a, b = offsets[g], offsets[g + 1]
+        want[a:b] = ob.port_warp(lo[a:b], mats[g])
+    assert not fields_equal(got, want.astype(api.SURFEL_DTYPE))
+
+
+def test_active_set_extract_append(mods):
+    """move_add_surfels on the resident map (surfel_map.cpp:1476-1497, 1583-1590), then keep fusing."""
+    api, synth, ob = mods
+    cam, scene = synth.VGA_DRIVE, synth.Scene(seed=31)
+    n = 12
+    frames = list(synth.sequence(cam, scene, n))
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 20)
+    orc = ob.PortOracle(cam)
+    for t, img, dep, pose, ref in frames:
+        ff.frame_upload(t, img, dep)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    parked = None
+    for t, img, dep, pose, ref in frames:
+        if t == 7:  # keyframe 0 leaves the active set
+            lo, want = ob.port_extract_key(lo, 0)
+            got = ff.map_extract(0)
+            assert len(got) == len(want) > 0
+            assert not fields_equal(got, want.astype(api.SURFEL_DTYPE))
+            parked = got
+        if t == 10:  # ... and comes back
+            lo = np.concatenate([lo, parked.astype(ob.SURFEL_DTYPE)])
+            ff.map_append(parked)
+        ff.fuse_frame_resident(t, ref, pose)
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+        got_map = ff.map_download()
+        assert not fields_equal(got_map, lo.astype(api.SURFEL_DTYPE)), t
