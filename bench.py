@@ -121,13 +121,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DSM_BENCH_BACKEND=gloo + DSM_BENCH_ONE_DEVICE=1 run the multi-rank logic on a single GPU (tests only):
+    # every rank uses cuda:0 and the collectives run on CPU tensors.
+    backend = os.environ.get("DSM_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("DSM_BENCH_ONE_DEVICE", "0") == "1"
+    device = 0 if (world == 1 or one_device) else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = f"cuda:{device}" if backend == "nccl" else "cpu"
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    device = local_rank if world > 1 else 0
-    torch.cuda.set_device(device)
 
     cam = synth.KITTI_1226
     B, K, W = args.streams, args.steps, args.warmup
@@ -191,7 +198,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     m_end = [ff.map_size() for ff in handles]
@@ -205,7 +212,7 @@ def main():
             buf = torch.empty(m * 44, dtype=torch.uint8, device=f"cuda:{device}")
             ff.map_copy_to_device(buf.data_ptr(), m)
             clouds.append(buf)
-        merged, counts = merge_clouds(torch.cat(clouds))
+        merged, counts = merge_clouds(torch.cat(clouds).to(coll_dev))
         merged_total = int(sum(counts))
 
     frames_total = world * B * K

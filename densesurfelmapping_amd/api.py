@@ -47,6 +47,8 @@ ABI_SYMBOLS = (
     "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps",
+    "dsm_debug_run_stages", "dsm_debug_get_label_buffer", "dsm_debug_set_label_buffer", "dsm_debug_get_seed_state",
+    "dsm_debug_set_seed_state",
 )
 
 
@@ -114,6 +116,11 @@ def load_library():
     lib.dsm_get_seeds.argtypes = [_vp, _vp]
     lib.dsm_seed_count.argtypes = [_vp]
     lib.dsm_debug_wave_stamps.argtypes = [_vp, _vp]
+    lib.dsm_debug_run_stages.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]
+    lib.dsm_debug_get_label_buffer.argtypes = [_vp, C.c_int, _vp]
+    lib.dsm_debug_set_label_buffer.argtypes = [_vp, C.c_int, _vp]
+    lib.dsm_debug_get_seed_state.argtypes = [_vp, _vp, _vp]
+    lib.dsm_debug_set_seed_state.argtypes = [_vp, _vp, _vp]
     lib.dsm_replay_timed.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.POINTER(_StageTimes)]
     _lib = lib
     return lib
@@ -306,6 +313,36 @@ class FusionFunctions:
         out = np.zeros(self.n_seed, SEED_DTYPE)
         self._check(self._lib.dsm_get_seeds(self._h, _ptr(out)))
         return out
+
+    # ---- state-level test taps ---------------------------------------------------------------
+    STAGES = ("init_seeds", "assign_0", "update_seeds_0", "commit_seeds_0", "assign_1", "resolve_1", "update_seeds_1",
+              "commit_seeds_1", "assign_2", "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_planes", "fuse_surfels",
+              "frame_tail")
+
+    def debug_run_stages(self, slot, reference_frame_index, pose, first, last):
+        pose_cm = pose_to_colmajor(pose)
+        self._check(self._lib.dsm_debug_run_stages(self._h, slot, reference_frame_index, _ptr(pose_cm),
+                                                   self.STAGES.index(first), self.STAGES.index(last)))
+
+    def debug_get_labels(self, which) -> np.ndarray:
+        out = np.zeros((self.height, self.width), np.int32)
+        self._check(self._lib.dsm_debug_get_label_buffer(self._h, which, _ptr(out)))
+        return out
+
+    def debug_set_labels(self, which, labels):
+        a = np.ascontiguousarray(labels, np.int32)
+        self._check(self._lib.dsm_debug_set_label_buffer(self._h, which, _ptr(a)))
+
+    def debug_get_seed_state(self):
+        core = np.zeros((self.n_seed, 4), np.float32)
+        stable = np.zeros(self.n_seed, np.int32)
+        self._check(self._lib.dsm_debug_get_seed_state(self._h, _ptr(core), _ptr(stable)))
+        return core, stable
+
+    def debug_set_seed_state(self, core, stable):
+        core = np.ascontiguousarray(core, np.float32)
+        stable = np.ascontiguousarray(stable, np.int32)
+        self._check(self._lib.dsm_debug_set_seed_state(self._h, _ptr(core), _ptr(stable)))
 
     def debug_wave_stamps(self) -> np.ndarray:
         out = np.zeros((4, self.n_seed, 8), np.int64)

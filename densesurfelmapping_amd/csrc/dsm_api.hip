@@ -608,6 +608,78 @@ int dsm_get_seeds(dsm_handle *h, dsm_seed *out) {
     return DSM_OK;
 }
 
+// ------------------------------------------------------------------ state-level test taps
+
+int dsm_debug_run_stages(dsm_handle *h, int slot, int reference_frame_index, const float *pose16, int first_stage,
+                         int last_stage) {
+    if (!h) return DSM_E_INVALID;
+    if (!pose16 || first_stage < 0 || last_stage >= kNumStages || first_stage > last_stage) return fail(h, DSM_E_INVALID, "bad stage range");
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->frames_done = h->frames_submitted;
+    if ((rc = stage_params(h, slot, reference_frame_index, pose16))) return rc; // ring slot of the current cursor
+    hipError_t e = launch_frame(h->d_ctx, h->hc, h->map_upper, true, h->stream, nullptr, first_stage, last_stage);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    if (last_stage == kNumStages - 1) { // the tail advanced the device cursor
+        h->frames_submitted++;
+        h->map_upper += h->hc.n_seed;
+        if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
+    }
+    return sync_and_fetch_counts(h);
+}
+
+int dsm_debug_get_label_buffer(dsm_handle *h, int which, int32_t *out) {
+    if (!h || !out || which < 0 || which > 1) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(out, (size_t)h->hc.w * 4, which ? h->hc.label_alt : h->hc.label, (size_t)h->hc.pitch * 4,
+                           (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+
+int dsm_debug_set_label_buffer(dsm_handle *h, int which, const int32_t *in) {
+    if (!h || !in || which < 0 || which > 1) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(which ? h->hc.label_alt : h->hc.label, (size_t)h->hc.pitch * 4, in, (size_t)h->hc.w * 4,
+                           (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyHostToDevice));
+    return DSM_OK;
+}
+
+int dsm_debug_get_seed_state(dsm_handle *h, float *core4, int32_t *stable) {
+    if (!h || !core4 || !stable) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t S = (size_t)h->hc.n_seed;
+    HIP_TRY(h, hipMemcpy(core4, h->hc.core, S * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(stable, h->hc.tmin, S * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < S; i++) stable[i] = stable[i] == kIntMax ? 1 : 0;
+    return DSM_OK;
+}
+
+int dsm_debug_set_seed_state(dsm_handle *h, const float *core4, const int32_t *stable) {
+    if (!h || !core4 || !stable) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t S = (size_t)h->hc.n_seed;
+    std::vector<double> inv(S);
+    std::vector<int32_t> t(S);
+    for (size_t i = 0; i < S; i++) {
+        inv[i] = 1.0 / (double)core4[4 * i + 3];
+        t[i] = stable[i] ? kIntMax : -1;
+    }
+    HIP_TRY(h, hipMemcpy(h->hc.core, core4, S * 16, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->hc.inv_depth, inv.data(), S * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->hc.tmin, t.data(), S * 4, hipMemcpyHostToDevice));
+    return DSM_OK;
+}
+
 // debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_WAVE_STAMPS=1)
 int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 4 * n_seed * 8 */) {
     if (!h || !out) return DSM_E_INVALID;

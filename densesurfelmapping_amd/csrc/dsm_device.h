@@ -83,7 +83,7 @@ constexpr int kStatusBadPick = 2;
 constexpr int kNumStages = 15;
 extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx *d_ctx, const DeviceCtx &h_ctx, int map_upper_bound, bool with_compaction,
-                        hipStream_t stream, hipEvent_t *ev);
+                        hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);
 
 hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st);

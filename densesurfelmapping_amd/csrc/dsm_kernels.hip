@@ -1110,9 +1110,14 @@ const char *const kStageNames[kNumStages] = {
 };
 
 hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
-                        hipStream_t st, hipEvent_t *ev) {
+                        hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi) {
     int stage = 0;
     hipError_t err = hipSuccess;
+// launches only the stages whose index (position in kStageNames) lies in [stage_lo, stage_hi]
+#define hipLaunchStage(...)                                   \
+    do {                                                      \
+        if (stage - 1 >= stage_lo && stage - 1 <= stage_hi) hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 #define DSM_MARK()                                                                      \
     do {                                                                                \
         if (ev) {                                                                       \
@@ -1131,39 +1136,40 @@ hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_b
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
-    hipLaunchKernelGGL(k_init_seeds, g_seed_thr, dim3(256), 0, st, d);
+    hipLaunchStage(k_init_seeds, g_seed_thr, dim3(256), 0, st, d);
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
-            hipLaunchKernelGGL(k_assign<true>, g_tile, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_assign<true>, g_tile, dim3(256), 0, st, d, sweep);
             DSM_MARK();
-            hipLaunchKernelGGL(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, d, sweep);
             DSM_MARK();
         } else {
-            hipLaunchKernelGGL(k_assign<false>, g_tile, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_assign<false>, g_tile, dim3(256), 0, st, d, sweep);
             DSM_MARK();
-            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_resolve, dim3(1), dim3(256), 0, st, d, sweep);
             DSM_MARK();
-            hipLaunchKernelGGL(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, d, sweep);
             DSM_MARK();
         }
-        hipLaunchKernelGGL(k_commit_seeds, g_seed_thr, dim3(256), 0, st, d, sweep);
+        hipLaunchStage(k_commit_seeds, g_seed_thr, dim3(256), 0, st, d, sweep);
         DSM_MARK();
     }
-    hipLaunchKernelGGL(k_seed_planes, g_seed_wave, dim3(256), 0, st, d);
+    hipLaunchStage(k_seed_planes, g_seed_wave, dim3(256), 0, st, d);
     DSM_MARK();
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;
     if (fuse_blocks > 2048) fuse_blocks = 2048;
-    hipLaunchKernelGGL(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, d);
+    hipLaunchStage(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, d);
     DSM_MARK();
-    hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1024), 0, st, d, with_compaction ? 1 : 0);
+    hipLaunchStage(k_frame_tail, dim3(1), dim3(1024), 0, st, d, with_compaction ? 1 : 0);
     DSM_MARK();
     if (ev) { // empty interval: what a pair of event records costs by itself
         err = hipEventRecord(ev[stage], st);
         if (err != hipSuccess) return err;
     }
 #undef DSM_MARK
+#undef hipLaunchStage
     return hipGetLastError();
 }
 

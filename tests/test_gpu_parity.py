@@ -342,3 +342,106 @@ def test_active_set_extract_append(mods):
         lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
         got_map = ff.map_download()
         assert not fields_equal(got_map, lo.astype(api.SURFEL_DTYPE)), t
+
+
+def _seed_state_equal(ff, orc, tag):
+    core, stable = ff.debug_get_seed_state()
+    sd = orc.seeds()
+    for k, f in enumerate(("x", "y", "mean_intensity", "mean_depth")):
+        a, b = core[:, k], sd[f]
+        same = (a.view("u4") == b.view("u4")) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), f"{tag}: seed field {f} differs at {np.nonzero(~same)[0][:5].tolist()}"
+    assert np.array_equal(stable.astype(bool), sd["stable"].astype(bool)), f"{tag}: stable flags differ"
+
+
+def test_state_level_early_return(mods):
+    """State-level test of FF.cpp:516-517 on the GPU: after the first assignment, give all pixels of a few
+    unstable superpixels to their neighbours, then run update_seeds on oracle and device.  The worker chunk
+    of each victim must be abandoned from the victim on (k_update_seeds staging + k_commit_seeds)."""
+    api, synth, ob = mods
+    cam = synth.TINY
+    img, dep, _ = synth.render(cam, synth.Scene(seed=8), 0)
+    pose = np.eye(4, dtype=np.float32)
+    gw = cam.width // 8
+    rng = np.random.default_rng(0)
+    for trial in range(5):
+        ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536, flags=api.DSM_FLAG_NO_GRAPH)
+        ff.frame_upload(0, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        orc = ob.PortOracle(cam)
+        orc.set_frame(img, dep)
+        orc.stage("initialize_seeds")
+        orc.stage("update_pixels")
+        ff.debug_run_stages(0, 0, pose, "init_seeds", "assign_0")
+        labels = ff.debug_get_labels(0)
+        assert np.array_equal(labels, orc.labels())
+        for victim in rng.choice(ff.n_seed, size=1 + trial, replace=False):
+            victim = int(victim)
+            neighbour = victim + 1 if (victim % gw) + 1 < gw else victim - 1
+            labels[labels == victim] = neighbour  # the victim now owns nothing
+        ff.debug_set_labels(0, labels)
+        orc.set_labels(labels)
+        ff.debug_run_stages(0, 0, pose, "update_seeds_0", "commit_seeds_0")
+        orc.stage("update_seeds")
+        _seed_state_equal(ff, orc, f"trial {trial} sweep 0")
+        # and one more full sweep on top of the abandoned chunks
+        ff.debug_run_stages(0, 0, pose, "assign_1", "commit_seeds_1")
+        orc.stage("update_pixels")
+        assert np.array_equal(ff.debug_get_labels(1), orc.labels()), trial
+        orc.stage("update_seeds")
+        _seed_state_equal(ff, orc, f"trial {trial} sweep 1")
+        ff.close()
+
+
+def test_state_level_stable_skip(mods):
+    """State-level test of the sequential `stable` skip rule (FF.cpp:400,445,450): random stable flags on
+    half of the superpixels, so that many pixels sit between two stable seeds and the worklist fixed point of
+    k_assign / k_resolve has real work; labels and seeds after the sweep must equal the row-major scan's."""
+    api, synth, ob = mods
+    cam = synth.TINY
+    pose = np.eye(4, dtype=np.float32)
+    rng = np.random.default_rng(1)
+    for trial in range(6):
+        img, dep, _ = synth.render(cam, synth.Scene(seed=20 + trial, intensity_noise=60.0), trial)
+        ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536, flags=api.DSM_FLAG_NO_GRAPH)
+        ff.frame_upload(0, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        orc = ob.PortOracle(cam)
+        orc.set_frame(img, dep)
+        orc.stage("initialize_seeds")
+        orc.stage("update_pixels")
+        orc.stage("update_seeds")
+        ff.debug_run_stages(0, 0, pose, "init_seeds", "commit_seeds_0")
+        _seed_state_equal(ff, orc, f"trial {trial} before")
+        sd = orc.seeds()
+        flags = rng.random(len(sd)) < (0.3 + 0.1 * trial)
+        sd["stable"] = flags
+        orc.set_seeds(sd)
+        core, _ = ff.debug_get_seed_state()
+        ff.debug_set_seed_state(core, flags.astype(np.int32))
+        for sweep in (1, 2):
+            ff.debug_run_stages(0, 0, pose, f"assign_{sweep}", f"commit_seeds_{sweep}")
+            orc.stage("update_pixels")
+            got, want = ff.debug_get_labels(sweep & 1), orc.labels()
+            assert np.array_equal(got, want), f"trial {trial} sweep {sweep}: {int((got != want).sum())} labels differ"
+            orc.stage("update_seeds")
+            _seed_state_equal(ff, orc, f"trial {trial} sweep {sweep}")
+        ff.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
+    sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--streams", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["final_surfels_all_ranks"] > 0
+    assert "cpu_baseline" not in out  # rank 0 at N=1 only
