@@ -89,6 +89,56 @@ def test_resident_replay_kitti(mods):
         _compare_frame(f"kitti frame {t}", ff, orc, ff.map_download(), lo.astype(api.SURFEL_DTYPE))
 
 
+@pytest.mark.parametrize("camera,frames", [("KITTI_1241", 4), ("FULLHD", 2)])
+def test_other_baseline_sizes(mods, camera, frames):
+    """The launch-file default 1241x376 (ragged: 1241 = 155*8 + 1) and BASELINE config 5's 1920x1080, against
+    the oracle frame by frame."""
+    api, synth, ob = mods
+    cam, scene = getattr(synth, camera), synth.Scene(seed=77)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
+    orc = ob.PortOracle(cam)
+    lg = np.zeros(0, api.SURFEL_DTYPE)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, frames):
+        lg, kg = ff.fuse_map(ref, img, dep, pose, lg)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert kg == ko
+        _compare_frame(f"{camera} frame {t}", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+
+
+def test_api_errors_are_reported(mods):
+    """The reference returns void and prints; the ABI returns a status and a message, and never computes on bad input."""
+    api, synth, ob = mods
+    cam = synth.TINY
+    with pytest.raises(api.DsmError) as ei:  # (size mod 8) > 4: the reference would index seeds[-1]
+        api.FusionFunctions().initialize(165, 96, 100, 100, 80, 48, 30, 0.5)
+    assert ei.value.code == -1
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=128, frame_slots=2)
+    img, dep, pose = synth.render(cam, synth.Scene(), 0)
+    with pytest.raises(api.DsmError) as ei:  # resident call before a map exists
+        ff.fuse_frame_resident(0, 0, pose)
+    assert ei.value.code == -5
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    with pytest.raises(api.DsmError) as ei:  # slot out of range
+        ff.frame_upload(2, img, dep)
+    assert ei.value.code == -1
+    with pytest.raises(api.DsmError) as ei:  # more surfels than the handle can hold
+        ff.map_upload(np.zeros(1000, api.SURFEL_DTYPE))
+    assert ei.value.code == -4
+    with pytest.raises(ValueError):
+        ff.fuse_map(0, img[:, :-1], dep, pose, np.zeros(0, api.SURFEL_DTYPE))
+    # capacity overflow while appending new surfels is reported, not silently truncated
+    ff.frame_upload(0, img, dep)
+    nearly_full = np.zeros(120, api.SURFEL_DTYPE)  # live surfels far behind the camera: never touched, never holes
+    nearly_full["pz"] = -50.0
+    nearly_full["update_times"] = 9
+    ff.map_upload(nearly_full)
+    ff.fuse_frame_resident(0, 0, pose)  # ~30 new surfels do not fit into the remaining 8 slots
+    with pytest.raises(api.DsmError) as ei:
+        ff.synchronize()
+    assert ei.value.code == -4
+
+
 def test_batched_replay_matches_stepwise(mods):
     """dsm_replay_enqueue of a whole subsequence (no host sync in between) == frame-by-frame."""
     api, synth, ob = mods
