@@ -29,8 +29,7 @@ struct dsm_handle {
     dsm_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    DeviceCtx hc;              // host copy of the device context
-    DeviceCtx *d_ctx = nullptr;
+    DeviceCtx hc;              // the context, passed by value to every kernel
     std::vector<void *> allocs; // every hipMalloc of this handle
     FrameParams *h_params = nullptr; // pinned staging ring
     int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
@@ -131,7 +130,7 @@ int ensure_graph(dsm_handle *h, bool with_compaction) {
     if (ge) return DSM_OK;
     hipGraph_t g = nullptr;
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t le = launch_frame(h->d_ctx, h->hc, fuse_grid_bound(h), with_compaction, h->stream, nullptr);
+    hipError_t le = launch_frame(h->hc, fuse_grid_bound(h), with_compaction, h->stream, nullptr);
     hipError_t ce = hipStreamEndCapture(h->stream, &g);
     if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
     if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
@@ -144,7 +143,7 @@ int ensure_graph(dsm_handle *h, bool with_compaction) {
 // enqueue the kernels of one frame whose params were staged by stage_params
 int submit_frame(dsm_handle *h, bool with_compaction) {
     if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
-        hipError_t e = launch_frame(h->d_ctx, h->hc, h->map_upper, with_compaction, h->stream, nullptr);
+        hipError_t e = launch_frame(h->hc, h->map_upper, with_compaction, h->stream, nullptr);
         if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     } else {
         int rc = ensure_graph(h, with_compaction);
@@ -316,11 +315,10 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
     CREATE_TRY(dev_alloc(h, &h->d_warp, 16));
-    CREATE_TRY(dev_alloc(h, &h->d_ctx, 1));
+    CREATE_TRY(dev_alloc(h, &c.cur, 1));
     CREATE_TRY(hipHostMalloc((void **)&h->h_params, sizeof(FrameParams) * kParamRing, hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 256, hipHostMallocDefault));
     memset(h->h_scalars, 0, 256);
-    CREATE_TRY(hipMemcpyAsync(h->d_ctx, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
     for (int i = 0; i <= kNumStages + 1; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
     h->have_events = true;
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -493,7 +491,7 @@ int dsm_map_extract(dsm_handle *h, int32_t key, dsm_surfel *out, int32_t cap, in
     const int m = h->h_scalars[0];
     dsm_surfel *d_out = nullptr;
     HIP_TRY(h, hipMalloc((void **)&d_out, sizeof(dsm_surfel) * (size_t)(m > 0 ? m : 1)));
-    hipError_t e = launch_extract(h->d_ctx, key, d_out, m, m, h->stream);
+    hipError_t e = launch_extract(h->hc, key, d_out, m, m, h->stream);
     int32_t k = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h->h_scalars[3], h->hc.n_holes, 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -517,7 +515,7 @@ int dsm_map_append(dsm_handle *h, const dsm_surfel *surfels, int32_t n) {
     const int m = h->h_scalars[0];
     if (m + n > h->hc.cap) return fail(h, DSM_E_CAPACITY, "%d + %d surfels exceed the handle's capacity %d", m, n, h->hc.cap);
     if (n) HIP_TRY(h, hipMemcpy(h->hc.local + m, surfels, sizeof(dsm_surfel) * (size_t)n, hipMemcpyHostToDevice));
-    hipError_t e = launch_append_count(h->d_ctx, n, h->stream);
+    hipError_t e = launch_append_count(h->hc, n, h->stream);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "append: %s", hipGetErrorString(e));
     h->map_upper = m + n;
     return DSM_OK;
@@ -620,7 +618,7 @@ int dsm_debug_run_stages(dsm_handle *h, int slot, int reference_frame_index, con
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frames_done = h->frames_submitted;
     if ((rc = stage_params(h, slot, reference_frame_index, pose16))) return rc; // ring slot of the current cursor
-    hipError_t e = launch_frame(h->d_ctx, h->hc, h->map_upper, true, h->stream, nullptr, first_stage, last_stage);
+    hipError_t e = launch_frame(h->hc, h->map_upper, true, h->stream, nullptr, first_stage, last_stage);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     if (last_stage == kNumStages - 1) { // the tail advanced the device cursor
         h->frames_submitted++;
@@ -706,7 +704,7 @@ int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32
     }
     for (int i = 0; i < n; i++) {
         if ((rc = stage_params(h, slots[i], ref_idx[i], poses16 + 16 * (size_t)i))) return rc;
-        hipError_t e = launch_frame(h->d_ctx, h->hc, h->map_upper, true, h->stream, h->ev);
+        hipError_t e = launch_frame(h->hc, h->map_upper, true, h->stream, h->ev);
         if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         h->frames_submitted++;
         if ((rc = sync_and_fetch_counts(h))) return rc;

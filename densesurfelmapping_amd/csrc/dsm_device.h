@@ -20,7 +20,17 @@ struct FrameParams {
     int32_t pad[2];
 };
 
-// Everything a kernel needs, in one struct in device memory (kernels take a single pointer).
+// The frame being processed: written to device memory by k_init_seeds (first kernel of a frame) from
+// params[cursor % n_params], read by every later kernel of the frame.
+struct FrameCur {
+    FrameParams p;
+    const uint8_t *img;
+    const float *dep;
+};
+
+// Everything a kernel needs.  Passed to every kernel BY VALUE (kernel-argument segment): the pointers and
+// sizes never change after dsm_create, so a captured graph stays valid, and a kernel reaches its data
+// without first loading a context from memory (one dependent round trip less per kernel).
 struct DeviceCtx {
     // geometry
     int32_t w, h, pitch; // pitch = row stride in elements of every image-shaped plane (multiple of 64)
@@ -65,11 +75,7 @@ struct DeviceCtx {
     int32_t n_params;
     int32_t *cursor;
     int32_t *status; // sticky device-side error bits
-    // the frame being processed: written by k_init_seeds (first kernel of a frame) from
-    // params[cursor % n_params], read by every later kernel of the frame with one scalar load
-    FrameParams cur;
-    const uint8_t *cur_img;
-    const float *cur_dep;
+    FrameCur *cur; // device memory, see FrameCur
     // optional per-wave phase stamps (shader clock) of the per-seed kernels; null unless DSM_WAVE_STAMPS=1
     long long *stamps; // [4 kernels][n_seed][8]
 };
@@ -82,12 +88,12 @@ constexpr int kStatusBadPick = 2;
 // the first kernel and after every kernel (ev[0..n_stages]).
 constexpr int kNumStages = 15;
 extern const char *const kStageNames[kNumStages];
-hipError_t launch_frame(const DeviceCtx *d_ctx, const DeviceCtx &h_ctx, int map_upper_bound, bool with_compaction,
+hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);
 
 hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st);
-hipError_t launch_extract(const DeviceCtx *d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st);
-hipError_t launch_append_count(const DeviceCtx *d, int n, hipStream_t st);
+hipError_t launch_extract(const DeviceCtx &ctx, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st);
+hipError_t launch_append_count(const DeviceCtx &ctx, int n, hipStream_t st);
 
 } // namespace dsm

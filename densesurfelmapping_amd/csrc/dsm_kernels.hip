@@ -120,27 +120,28 @@ __device__ __forceinline__ int seed_of_block(int b, int wv, int gw, int gh) {
     return (gx < gw && gy < gh) ? gy * gw + gx : -1;
 }
 
-__device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur; }
-__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return c->cur_img; }
-__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur_dep; }
+__device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur->p; }
+__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return c->cur->img; }
+__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur->dep; }
 
 // ------------------------------------------------------------------------------ init seeds
-__global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx *__restrict__ c) {
+__global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx) {
+    const DeviceCtx *__restrict__ c = &ctx;
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
     if (s == 0) c->work_count[0] = 0;
-    // first kernel of the frame: resolve the params ring once and publish the result in the context
+    // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
     const FrameParams &fp = c->params[(unsigned)c->cursor[0] % (unsigned)c->n_params];
     const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
     const float *dep = c->depth_base + (int64_t)fp.slot * c->slot_elems;
     if (blockIdx.x == 0 && threadIdx.x < 64) {
-        DeviceCtx *wc = const_cast<DeviceCtx *>(c);
+        FrameCur *wc = c->cur;
         const int t = threadIdx.x;
-        if (t < 16) wc->cur.pose[t] = fp.pose[t];
-        else if (t < 32) wc->cur.inv[t - 16] = fp.inv[t - 16];
-        else if (t == 32) { wc->cur.ref_idx = fp.ref_idx; wc->cur.slot = fp.slot; }
-        else if (t == 33) wc->cur_img = img;
-        else if (t == 34) wc->cur_dep = dep;
+        if (t < 16) wc->p.pose[t] = fp.pose[t];
+        else if (t < 32) wc->p.inv[t - 16] = fp.inv[t - 16];
+        else if (t == 32) { wc->p.ref_idx = fp.ref_idx; wc->p.slot = fp.slot; }
+        else if (t == 33) wc->img = img;
+        else if (t == 34) wc->dep = dep;
     }
     const int w = c->w, h = c->h, pitch = c->pitch;
     const bool live = s < c->n_seed;
@@ -225,7 +226,8 @@ __device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
     }
 }
 
-template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx *__restrict__ c, int sweep) {
+template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
     const FrameParams &fp = frame_params(c);
@@ -284,7 +286,8 @@ template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const Devi
 // One workgroup iterates the worklist to the fixed point.  (Folding this into k_assign behind a
 // "last block done" ticket costs a device-scope release per workgroup -- an L2 write-back on this
 // multi-XCD part -- and was 10x slower than the extra launch.)
-__global__ __launch_bounds__(256) void k_resolve(const DeviceCtx *__restrict__ c, int sweep) {
+__global__ __launch_bounds__(256) void k_resolve(const DeviceCtx ctx, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
     resolve_worklist(c, ((sweep - 1) & 1) ? c->label_alt : c->label);
 }
 
@@ -327,7 +330,8 @@ constexpr int kWin = 2 * kCell; // 16
 // APPLY (sweeps >= 1): the label image of this sweep is  new(p) = T[old(p)] < p ? pick(p) : old(p)  (see
 // k_assign); it is formed on the fly for the window, and every wave stores it for the pixels of its
 // own cell (ragged right/bottom pixels go to the last cell column/row) into the other label buffer.
-template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx *__restrict__ c, int sweep) {
+template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -454,7 +458,8 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(cons
 }
 
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
-__global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx *__restrict__ c, int sweep) {
+__global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s == 0) c->work_count[0] = 0;
     if (s >= c->n_seed) return;
@@ -525,7 +530,8 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict__ c) {
+__global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx ctx) {
+    const DeviceCtx *__restrict__ c = &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
@@ -735,7 +741,8 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx *__restrict
 // One lane per surfel, a wave per 64 consecutive surfels (so the deleted-slot bitmap is one ballot).
 // Pure gather: a surfel reads one depth pixel, one label and one seed and rewrites only itself;
 // the single shared write is the idempotent `fused` byte of the seed.
-__global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx *__restrict__ c) {
+__global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx) {
+    const DeviceCtx *__restrict__ c = &ctx;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int M = c->n_local[0];
@@ -964,7 +971,8 @@ __device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c) {
 // Frame tail in one workgroup: new surfels (ordered), deleted-slot list, order-exact compaction, then
 // commit the map size and bump the params cursor.  The phases are separated by a workgroup-scope fence +
 // barrier because later phases read what earlier ones (same workgroup) wrote to global memory.
-__global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx *__restrict__ c, int with_compaction) {
+__global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, int with_compaction) {
+    const DeviceCtx *__restrict__ c = &ctx;
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
     tail_new_surfels(c, s_cnt);
@@ -1043,7 +1051,8 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
 // ------------------------------------------------------------------------------ active-set maintenance
 // SM.cpp:1476-1497: bitmap of live surfels attached to keyframe `key` (reuses the hole bitmap arrays: they are
 // rebuilt by every frame), then the same one-workgroup scan, then an ordered copy-out that deletes the slots.
-__global__ __launch_bounds__(256) void k_mark_key(const DeviceCtx *__restrict__ c, int key) {
+__global__ __launch_bounds__(256) void k_mark_key(const DeviceCtx ctx, int key) {
+    const DeviceCtx *__restrict__ c = &ctx;
     const int M = c->n_local[0];
     const int n_wave = (M + 63) >> 6, lane = lane_id();
     const int waves_total = (gridDim.x * 256) >> 6;
@@ -1055,11 +1064,13 @@ __global__ __launch_bounds__(256) void k_mark_key(const DeviceCtx *__restrict__ 
         if (lane == 0) c->hole_mask[wv] = m;
     }
 }
-__global__ __launch_bounds__(1024) void k_scan_marks(const DeviceCtx *__restrict__ c) {
+__global__ __launch_bounds__(1024) void k_scan_marks(const DeviceCtx ctx) {
+    const DeviceCtx *__restrict__ c = &ctx;
     __shared__ int s_wave[17];
     tail_hole_scan(c, s_wave); // wave_prefix, holes (= marked indices, ascending), n_holes
 }
-__global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx *__restrict__ c, dsm_surfel *__restrict__ out, int cap) {
+__global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx ctx, dsm_surfel *__restrict__ out, int cap) {
+    const DeviceCtx *__restrict__ c = &ctx;
     const int k = c->n_holes[0];
     for (int j = blockIdx.x * 256 + threadIdx.x; j < k && j < cap; j += gridDim.x * 256) {
         const int i = c->holes[j];
@@ -1067,7 +1078,8 @@ __global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx *__restr
         c->local[i].update_times = 0;
     }
 }
-__global__ void k_append(const DeviceCtx *__restrict__ c, int n) {
+__global__ void k_append(const DeviceCtx ctx, int n) {
+    const DeviceCtx *__restrict__ c = &ctx;
     if (threadIdx.x == 0 && blockIdx.x == 0) c->n_local[0] = c->n_local[0] + n;
 }
 
@@ -1079,7 +1091,7 @@ hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, c
     hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, d_offsets, n_groups);
     return hipGetLastError();
 }
-hipError_t launch_extract(const DeviceCtx *d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st) {
+hipError_t launch_extract(const DeviceCtx &d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st) {
     int blocks = (n_upper + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
@@ -1088,7 +1100,7 @@ hipError_t launch_extract(const DeviceCtx *d, int key, dsm_surfel *out, int cap,
     hipLaunchKernelGGL(k_extract_marked, dim3(64), dim3(256), 0, st, d, out, cap);
     return hipGetLastError();
 }
-hipError_t launch_append_count(const DeviceCtx *d, int n, hipStream_t st) {
+hipError_t launch_append_count(const DeviceCtx &d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_append, dim3(1), dim3(64), 0, st, d, n);
     return hipGetLastError();
 }
@@ -1109,7 +1121,7 @@ const char *const kStageNames[kNumStages] = {
     "assign_2",   "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_planes", "fuse_surfels", "frame_tail",
 };
 
-hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
+hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
                         hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi) {
     int stage = 0;
     hipError_t err = hipSuccess;
@@ -1136,33 +1148,33 @@ hipError_t launch_frame(const DeviceCtx *d, const DeviceCtx &hc, int map_upper_b
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
-    hipLaunchStage(k_init_seeds, g_seed_thr, dim3(256), 0, st, d);
+    hipLaunchStage(k_init_seeds, g_seed_thr, dim3(256), 0, st, hc);
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
-            hipLaunchStage(k_assign<true>, g_tile, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_assign<true>, g_tile, dim3(256), 0, st, hc, sweep);
             DSM_MARK();
-            hipLaunchStage(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, hc, sweep);
             DSM_MARK();
         } else {
-            hipLaunchStage(k_assign<false>, g_tile, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_assign<false>, g_tile, dim3(256), 0, st, hc, sweep);
             DSM_MARK();
-            hipLaunchStage(k_resolve, dim3(1), dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_resolve, dim3(1), dim3(256), 0, st, hc, sweep);
             DSM_MARK();
-            hipLaunchStage(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, d, sweep);
+            hipLaunchStage(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, hc, sweep);
             DSM_MARK();
         }
-        hipLaunchStage(k_commit_seeds, g_seed_thr, dim3(256), 0, st, d, sweep);
+        hipLaunchStage(k_commit_seeds, g_seed_thr, dim3(256), 0, st, hc, sweep);
         DSM_MARK();
     }
-    hipLaunchStage(k_seed_planes, g_seed_wave, dim3(256), 0, st, d);
+    hipLaunchStage(k_seed_planes, g_seed_wave, dim3(256), 0, st, hc);
     DSM_MARK();
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;
     if (fuse_blocks > 2048) fuse_blocks = 2048;
-    hipLaunchStage(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, d);
+    hipLaunchStage(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, hc);
     DSM_MARK();
-    hipLaunchStage(k_frame_tail, dim3(1), dim3(1024), 0, st, d, with_compaction ? 1 : 0);
+    hipLaunchStage(k_frame_tail, dim3(1), dim3(1024), 0, st, hc, with_compaction ? 1 : 0);
     DSM_MARK();
     if (ev) { // empty interval: what a pair of event records costs by itself
         err = hipEventRecord(ev[stage], st);
