@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdsm_hip.so")
+LIB_PATH = os.environ.get("DSM_LIB_PATH") or os.path.join(HERE, "libdsm_hip.so")  # override: experiments only
 
 SURFEL_DTYPE = np.dtype(
     [("px", "<f4"), ("py", "<f4"), ("pz", "<f4"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"),
@@ -65,7 +65,7 @@ class _Config(C.Structure):
                 ("huber_range", C.c_double), ("baseline", C.c_double),
                 ("disparity_error", C.c_double), ("min_tolerate_diff", C.c_double),
                 ("device", C.c_int32), ("surfel_capacity", C.c_int32), ("frame_slots", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("pipeline_depth", C.c_int32)]
 
 
 class _StageTimes(C.Structure):
@@ -147,7 +147,7 @@ class FusionFunctions:
 
     # fusion_functions.h:84-87; the keyword arguments are what an HBM-resident engine adds
     def initialize(self, width, height, fx, fy, cx, cy, far_dist, near_dist, *, rgbd=False, device=0,
-                   surfel_capacity=0, frame_slots=0, flags=0):
+                   surfel_capacity=0, frame_slots=0, flags=0, pipeline_depth=0):
         self.close()
         cfg = _Config()
         rc = self._lib.dsm_config_init(C.byref(cfg), width, height, fx, fy, cx, cy, far_dist, near_dist,
@@ -155,6 +155,7 @@ class FusionFunctions:
         if rc:
             raise DsmError(rc, "dsm_config_init")
         cfg.device, cfg.surfel_capacity, cfg.frame_slots, cfg.flags = device, surfel_capacity, frame_slots, flags
+        cfg.pipeline_depth = pipeline_depth
         h = _vp()
         rc = self._lib.dsm_create(C.byref(cfg), C.byref(h))
         if rc:

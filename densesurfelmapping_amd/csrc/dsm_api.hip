@@ -28,15 +28,26 @@ constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 struct dsm_handle {
     dsm_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
-    DeviceCtx hc;              // the context, passed by value to every kernel
+    hipStream_t stream = nullptr; // the map stream: fuse + tail of every frame, in frame order; uploads; params
+    DeviceCtx hc;              // context of the pipeline that handled the latest frame (taps, shared pointers)
+    // Superpixel stages (init_seeds .. seed_planes) depend on the frame only, so frame f runs them on pipeline
+    // f % n_pipe -- its own stream and its own superpixel buffers -- while the map stream still fuses
+    // earlier frames.  fuse_surfels + frame_tail of frame f wait for them and run in frame order.
+    struct Pipe {
+        hipStream_t stream = nullptr;
+        DeviceCtx ctx;
+        hipGraphExec_t g_sp = nullptr, g_map[2] = {nullptr, nullptr}, g_all[2] = {nullptr, nullptr};
+        hipEvent_t ev_sp = nullptr, ev_map = nullptr;
+    } pipe[8];
+    int n_pipe = 1;
+    unsigned params_pending = 0; // bit p: pipeline p has not yet waited for the latest params upload
+    hipStream_t copy_stream = nullptr; // per-frame params go up here, so that they never queue behind the map stream
+    hipEvent_t ev_params = nullptr;
     std::vector<void *> allocs; // every hipMalloc of this handle
     FrameParams *h_params = nullptr; // pinned staging ring
     int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
     FrameParams *d_params = nullptr;
     float *d_warp = nullptr; // 16 floats
-    hipGraphExec_t graph[2] = {nullptr, nullptr}; // [with_compaction]
-    int graph_fuse_bound = 0;
     int64_t frames_submitted = 0, frames_done = 0;
     int map_upper = 0; // host-side upper bound of the resident map size
     bool map_valid = false;
@@ -97,7 +108,13 @@ int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16) {
     fp.ref_idx = ref_idx;
     fp.slot = slot;
     fp.pad[0] = fp.pad[1] = 0;
-    HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, &fp, sizeof fp, hipMemcpyHostToDevice, h->stream));
+    if (h->n_pipe == 1) { // everything is on one stream: stream order is enough
+        HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, &fp, sizeof fp, hipMemcpyHostToDevice, h->stream));
+        return DSM_OK;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, &fp, sizeof fp, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(h, hipEventRecord(h->ev_params, h->copy_stream));
+    h->params_pending = ~0u;
     return DSM_OK;
 }
 
@@ -118,42 +135,104 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
         fp.slot = slots[i];
         fp.pad[0] = fp.pad[1] = 0;
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    if (h->n_pipe == 1) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(h, hipEventRecord(h->ev_params, h->copy_stream));
+        h->params_pending = ~0u;
+    }
     *staged = m;
     return DSM_OK;
 }
 
 int fuse_grid_bound(const dsm_handle *h) { return h->hc.cap; }
 
-int ensure_graph(dsm_handle *h, bool with_compaction) {
-    hipGraphExec_t &ge = h->graph[with_compaction ? 1 : 0];
-    if (ge) return DSM_OK;
+int capture(dsm_handle *h, hipStream_t st, const DeviceCtx &ctx, bool with_compaction, int lo, int hi, hipGraphExec_t *out) {
+    if (*out) return DSM_OK;
     hipGraph_t g = nullptr;
-    HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t le = launch_frame(h->hc, fuse_grid_bound(h), with_compaction, h->stream, nullptr);
-    hipError_t ce = hipStreamEndCapture(h->stream, &g);
+    HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    hipError_t le = launch_frame(ctx, fuse_grid_bound(h), with_compaction, st, nullptr, lo, hi);
+    hipError_t ce = hipStreamEndCapture(st, &g);
     if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
     if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-    hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipError_t ie = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
     if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
     return DSM_OK;
 }
 
-// enqueue the kernels of one frame whose params were staged by stage_params
+// enqueue the kernels of one frame whose params were staged by stage_params: superpixel stages on the
+// frame's pipeline stream, fuse + tail on the map stream
 int submit_frame(dsm_handle *h, bool with_compaction) {
-    if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
-        hipError_t e = launch_frame(h->hc, h->map_upper, with_compaction, h->stream, nullptr);
-        if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    const int p = (int)(h->frames_submitted % h->n_pipe);
+    dsm_handle::Pipe &pp = h->pipe[p];
+    const bool eager = (h->cfg.flags & DSM_FLAG_NO_GRAPH) != 0;
+    const int wc = with_compaction ? 1 : 0;
+    if (h->n_pipe == 1) { // everything on the map stream, one graph
+        if (eager) {
+            hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, nullptr);
+            if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+        } else {
+            int rc = capture(h, h->stream, pp.ctx, with_compaction, 0, kNumStages - 1, &pp.g_all[wc]);
+            if (rc) return rc;
+            HIP_TRY(h, hipGraphLaunch(pp.g_all[wc], h->stream));
+        }
     } else {
-        int rc = ensure_graph(h, with_compaction);
-        if (rc) return rc;
-        HIP_TRY(h, hipGraphLaunch(h->graph[with_compaction ? 1 : 0], h->stream));
+        // the pipeline's buffers are free once the map stream has finished the frame that used them last,
+        // and the frame's params must have landed
+        HIP_TRY(h, hipStreamWaitEvent(pp.stream, pp.ev_map, 0));
+        if (h->params_pending & (1u << p)) {
+            HIP_TRY(h, hipStreamWaitEvent(pp.stream, h->ev_params, 0));
+            h->params_pending &= ~(1u << p);
+        }
+        if (eager) {
+            hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, pp.stream, nullptr, 0, kLastSuperpixelStage);
+            if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+        } else {
+            int rc = capture(h, pp.stream, pp.ctx, with_compaction, 0, kLastSuperpixelStage, &pp.g_sp);
+            if (rc) return rc;
+            HIP_TRY(h, hipGraphLaunch(pp.g_sp, pp.stream));
+        }
+        HIP_TRY(h, hipEventRecord(pp.ev_sp, pp.stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, pp.ev_sp, 0));
+        if (eager) {
+            hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
+            if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+        } else {
+            int rc = capture(h, h->stream, pp.ctx, with_compaction, kLastSuperpixelStage + 1, kNumStages - 1, &pp.g_map[wc]);
+            if (rc) return rc;
+            HIP_TRY(h, hipGraphLaunch(pp.g_map[wc], h->stream));
+        }
     }
+    if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+    h->hc = pp.ctx; // taps read the state of the latest frame
     h->frames_submitted++;
     if (with_compaction) {
         h->map_upper += h->hc.n_seed;
         if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
+    }
+    return DSM_OK;
+}
+
+// run some or all stages of the next frame serially on the map stream (timed replays, state-level taps)
+int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, int hi) {
+    const int p = (int)(h->frames_submitted % h->n_pipe);
+    dsm_handle::Pipe &pp = h->pipe[p];
+    if (h->n_pipe > 1 && (h->params_pending & 0x100u)) {
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
+        h->params_pending &= ~0x100u;
+    }
+    hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, ev, lo, hi);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+    h->hc = pp.ctx;
+    if (hi == kNumStages - 1) { // the tail advanced the pipeline's cursor
+        h->frames_submitted++;
+        if (with_compaction) {
+            h->map_upper += h->hc.n_seed;
+            if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
+        }
     }
     return DSM_OK;
 }
@@ -290,32 +369,57 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &img, (size_t)c.slot_elems * c.n_slots));
     CREATE_TRY(dev_alloc(h, &dep, (size_t)c.slot_elems * c.n_slots));
     c.img_base = img; c.depth_base = dep;
-    CREATE_TRY(dev_alloc(h, &c.label, (size_t)c.slot_elems));
-    CREATE_TRY(dev_alloc(h, &c.label_alt, (size_t)c.slot_elems));
-    CREATE_TRY(dev_alloc(h, &c.cand, (size_t)c.slot_elems));
-    CREATE_TRY(dev_alloc(h, &c.worklist, (size_t)c.slot_elems));
-    CREATE_TRY(dev_alloc(h, &c.core, (size_t)c.n_seed));
-    CREATE_TRY(dev_alloc(h, &c.inv_depth, (size_t)c.n_seed));
-    CREATE_TRY(dev_alloc(h, &c.core_stage, (size_t)c.n_seed));
-    CREATE_TRY(dev_alloc(h, &c.stable_stage, (size_t)c.n_seed));
-    CREATE_TRY(dev_alloc(h, &c.tmin, (size_t)c.n_seed));
-    CREATE_TRY(dev_alloc(h, &c.first_empty, (size_t)kSweeps * kWorkers));
-    CREATE_TRY(dev_alloc(h, &c.seeds, (size_t)c.n_seed));
     CREATE_TRY(dev_alloc(h, &c.local, (size_t)c.cap));
     CREATE_TRY(dev_alloc(h, &c.fresh, (size_t)c.n_seed));
     CREATE_TRY(dev_alloc(h, &c.hole_mask, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.wave_prefix, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.holes, (size_t)c.cap));
-    int32_t *scalars = nullptr; // work_count, n_local, n_local_next, n_new, n_holes, cursor, status
+    int32_t *scalars = nullptr; // shared: n_local, n_local_next, n_new, n_holes, status
     CREATE_TRY(dev_alloc(h, &scalars, 64));
-    c.work_count = scalars + 0; c.n_local = scalars + 8; c.n_local_next = scalars + 16; c.n_new = scalars + 24;
-    c.n_holes = scalars + 32; c.cursor = scalars + 40; c.status = scalars + 48; c.assign_done = scalars + 56;
-    if (const char *e = getenv("DSM_WAVE_STAMPS"))
-        if (e[0] == '1') CREATE_TRY(dev_alloc(h, &c.stamps, (size_t)4 * c.n_seed * 8));
+    c.n_local = scalars + 8; c.n_local_next = scalars + 16; c.n_new = scalars + 24;
+    c.n_holes = scalars + 32; c.status = scalars + 48;
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
     CREATE_TRY(dev_alloc(h, &h->d_warp, 16));
-    CREATE_TRY(dev_alloc(h, &c.cur, 1));
+    // per-pipeline superpixel state
+    int np = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
+    if (np != 1 && np != 2 && np != 4 && np != 8) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4 or 8"); return bail(DSM_E_INVALID); }
+    h->n_pipe = np;
+    if (np > 1) {
+        CREATE_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
+        CREATE_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    }
+    for (int p = 0; p < np; p++) {
+        dsm_handle::Pipe &pp = h->pipe[p];
+        pp.ctx = c;
+        DeviceCtx &q = pp.ctx;
+        q.cursor_mul = np; q.cursor_add = p;
+        if (np > 1) {
+            CREATE_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
+            CREATE_TRY(hipEventCreateWithFlags(&pp.ev_sp, hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&pp.ev_map, hipEventDisableTiming));
+        }
+        CREATE_TRY(dev_alloc(h, &q.label, (size_t)c.slot_elems));
+        CREATE_TRY(dev_alloc(h, &q.label_alt, (size_t)c.slot_elems));
+        CREATE_TRY(dev_alloc(h, &q.cand, (size_t)c.slot_elems));
+        CREATE_TRY(dev_alloc(h, &q.worklist, (size_t)c.slot_elems));
+        CREATE_TRY(dev_alloc(h, &q.core, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.inv_depth, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.core_stage, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.stable_stage, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.tmin, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.first_empty, (size_t)kSweeps * kWorkers));
+        CREATE_TRY(dev_alloc(h, &q.seeds, (size_t)c.n_seed));
+        int32_t *ps = nullptr; // work_count, cursor, assign_done
+        CREATE_TRY(dev_alloc(h, &ps, 64));
+        q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16;
+        CREATE_TRY(dev_alloc(h, &q.cur, 1));
+        if (const char *e = getenv("DSM_WAVE_STAMPS"))
+            if (e[0] == '1') CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)4 * c.n_seed * 8));
+        q.params = h->d_params;
+        if (np > 1) CREATE_TRY(hipEventRecord(pp.ev_map, h->stream)); // "buffers free"
+    }
+    h->hc = h->pipe[0].ctx;
     CREATE_TRY(hipHostMalloc((void **)&h->h_params, sizeof(FrameParams) * kParamRing, hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 256, hipHostMallocDefault));
     memset(h->h_scalars, 0, 256);
@@ -332,8 +436,20 @@ void dsm_destroy(dsm_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; i++)
-        if (h->graph[i]) (void)hipGraphExecDestroy(h->graph[i]);
+    for (int p = 0; p < 8; p++) {
+        dsm_handle::Pipe &pp = h->pipe[p];
+        if (pp.stream) (void)hipStreamSynchronize(pp.stream);
+        if (pp.g_sp) (void)hipGraphExecDestroy(pp.g_sp);
+        for (int i = 0; i < 2; i++) {
+            if (pp.g_map[i]) (void)hipGraphExecDestroy(pp.g_map[i]);
+            if (pp.g_all[i]) (void)hipGraphExecDestroy(pp.g_all[i]);
+        }
+        if (pp.ev_sp) (void)hipEventDestroy(pp.ev_sp);
+        if (pp.ev_map) (void)hipEventDestroy(pp.ev_map);
+        if (pp.stream) (void)hipStreamDestroy(pp.stream);
+    }
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
     for (void *p : h->allocs) (void)hipFree(p);
@@ -618,13 +734,7 @@ int dsm_debug_run_stages(dsm_handle *h, int slot, int reference_frame_index, con
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frames_done = h->frames_submitted;
     if ((rc = stage_params(h, slot, reference_frame_index, pose16))) return rc; // ring slot of the current cursor
-    hipError_t e = launch_frame(h->hc, h->map_upper, true, h->stream, nullptr, first_stage, last_stage);
-    if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
-    if (last_stage == kNumStages - 1) { // the tail advanced the device cursor
-        h->frames_submitted++;
-        h->map_upper += h->hc.n_seed;
-        if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
-    }
+    if ((rc = submit_serial(h, true, nullptr, first_stage, last_stage))) return rc;
     return sync_and_fetch_counts(h);
 }
 
@@ -704,9 +814,7 @@ int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32
     }
     for (int i = 0; i < n; i++) {
         if ((rc = stage_params(h, slots[i], ref_idx[i], poses16 + 16 * (size_t)i))) return rc;
-        hipError_t e = launch_frame(h->hc, h->map_upper, true, h->stream, h->ev);
-        if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
-        h->frames_submitted++;
+        if ((rc = submit_serial(h, true, h->ev, 0, kNumStages - 1))) return rc;
         if ((rc = sync_and_fetch_counts(h))) return rc;
         for (int s = 0; s < kNumStages; s++) {
             float ms = 0.0f;

@@ -73,7 +73,8 @@ struct DeviceCtx {
     // sequencing
     const FrameParams *params;
     int32_t n_params;
-    int32_t *cursor;
+    int32_t *cursor;      // frames this pipeline has finished; its next frame is params[cursor * cursor_mul + cursor_add]
+    int32_t cursor_mul, cursor_add;
     int32_t *status; // sticky device-side error bits
     FrameCur *cur; // device memory, see FrameCur
     // optional per-wave phase stamps (shader clock) of the per-seed kernels; null unless DSM_WAVE_STAMPS=1
@@ -87,6 +88,7 @@ constexpr int kStatusBadPick = 2;
 // otherwise FusionFunctions::fuse_initialize_map.  If ev != nullptr, an event is recorded before
 // the first kernel and after every kernel (ev[0..n_stages]).
 constexpr int kNumStages = 15;
+constexpr int kLastSuperpixelStage = 12; // init_seeds .. seed_planes need the frame only; fuse_surfels + frame_tail need the map
 extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx) {
     if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
     if (s == 0) c->work_count[0] = 0;
     // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
-    const FrameParams &fp = c->params[(unsigned)c->cursor[0] % (unsigned)c->n_params];
+    const FrameParams &fp = c->params[(unsigned)(c->cursor[0] * c->cursor_mul + c->cursor_add) % (unsigned)c->n_params];
     const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
     const float *dep = c->depth_base + (int64_t)fp.slot * c->slot_elems;
     if (blockIdx.x == 0 && threadIdx.x < 64) {

@@ -85,6 +85,8 @@ typedef struct dsm_config {
     int32_t surfel_capacity;  /* max resident surfels; 0 = default (4 Mi) */
     int32_t frame_slots;      /* resident frame slots in HBM; 0 = default (2) */
     uint32_t flags;           /* DSM_FLAG_* */
+    int32_t pipeline_depth;   /* frames of one sequence whose superpixel stages may be in flight at once
+                                 (1, 2, 4 or 8); 0 = default (4).  Results do not depend on it. */
 } dsm_config;
 
 #define DSM_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying a hipGraph */

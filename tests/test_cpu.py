@@ -266,7 +266,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.dsm_abi_version.restype = C.c_int
     assert lib.dsm_abi_version() == 1
-    assert C.sizeof(api._Config) == 80  # 8 x 4 B + 4 doubles + 4 x 4 B
+    assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
 
 
 def test_no_cpu_fallback_without_gpu():
