@@ -224,6 +224,9 @@ def main():
         merged, counts = merge_clouds(torch.cat(clouds).to(coll_dev))
         merged_total = int(sum(counts))
 
+    for ff in handles:  # the extra measurements below run alone on the GPU
+        ff.close()
+    handles = []
     frames_total = world * B * K
     fps = frames_total / dt
     m_avg = float(np.mean([(a + b) / 2 for a, b in zip(m_start, m_end)]))
