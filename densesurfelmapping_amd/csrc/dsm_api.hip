@@ -410,6 +410,10 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.tmin, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.first_empty, (size_t)kSweeps * kWorkers));
         CREATE_TRY(dev_alloc(h, &q.seeds, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.spawn_rec, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.spawn_ok, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.fused_flag, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.spawn_idx, (size_t)c.n_seed));
         int32_t *ps = nullptr; // work_count, cursor, assign_done
         CREATE_TRY(dev_alloc(h, &ps, 64));
         q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16;

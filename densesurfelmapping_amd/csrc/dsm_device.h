@@ -59,6 +59,12 @@ struct DeviceCtx {
     int32_t *worklist;    // pixel keys whose old and new seeds were both stable at sweep start
     int32_t *work_count;
     dsm_seed *seeds; // [S] final seed table, reference layout
+    // what initialize_surfels (FF.cpp:315-361) would create from each seed, prepared by k_seed_planes (every
+    // input but the `fused` flag is known there): the surfel, whether the seed qualifies, the flag itself
+    dsm_surfel *spawn_rec; // [S]
+    uint8_t *spawn_ok;     // [S]
+    uint8_t *fused_flag;   // [S] set by k_fuse_surfels (besides the byte in `seeds`)
+    int32_t *spawn_idx;    // [S] seeds that do create a surfel, ascending
     // surfel map
     dsm_surfel *local;
     int32_t cap;

@@ -734,7 +734,25 @@ __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx ctx) {
     }
     stamp(c, 3, s, 5, lane);
     if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
-    if (lane == 0) c->seeds[s] = out;
+    if (lane == 0) {
+        c->seeds[s] = out;
+        // initialize_surfels, FF.cpp:315-361, up to the `fused` test (k_frame_tail applies it)
+        SeedView sd;
+        sd.size = out.size; sd.nx = out.norm_x; sd.ny = out.norm_y; sd.nz = out.norm_z;
+        sd.px = out.posi_x; sd.py = out.posi_y; sd.pz = out.posi_z;
+        sd.view_cos = out.view_cos; sd.mean_depth = out.mean_depth; sd.mean_intensity = out.mean_intensity;
+        const bool ok = seed_spawns(sd, false);
+        if (ok) {
+            const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
+            dsm_surfel o;
+            o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
+            o.size = e.size; o.color = e.color; o.weight = e.weight;
+            o.update_times = e.update_times; o.last_update = e.last_update;
+            c->spawn_rec[s] = o;
+        }
+        c->spawn_ok[s] = ok ? 1 : 0;
+        c->fused_flag[s] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------ fuse surfels
@@ -775,7 +793,7 @@ __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx) {
                 sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
                 sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
                 oc = fuse_update(fc, ref_idx, fp.pose, e, pc, nc, dep[p], sd);
-                if (oc == kFuseFused) c->seeds[sidx].fused = 1;
+                if (oc == kFuseFused) { c->seeds[sidx].fused = 1; c->fused_flag[sidx] = 1; }
             }
             if (oc == kFuseDeleted) {
                 c->local[i].update_times = 0;
@@ -818,37 +836,29 @@ __device__ __forceinline__ int block_scan_1024(int v, int &excl, int *s_wave /* 
 
 // ------------------------------------------------------------------------------ new surfels
 // initialize_surfels: seeds in index order -> ordered stream compaction by one workgroup.
+// initialize_surfels (FF.cpp:315-361) as an ordered stream compaction by one workgroup.  k_seed_planes left
+// the would-be surfel of every qualifying seed in spawn_rec / spawn_ok; what remains is the `fused` test,
+// the ordered list of creating seeds (spawn_idx) and, without compaction, the copy into `fresh`.
 constexpr int kMaxSeedRounds = 64; // seeds <= 64 * 1024 (checked by dsm_create)
 
-__device__ __forceinline__ void tail_new_surfels(const DeviceCtx *__restrict__ c, int *s_cnt /* [kMaxSeedRounds*16+1] */) {
-    const FrameParams &fp = frame_params(c);
-    const Intrinsics K = c->k;
+__device__ __forceinline__ int tail_spawn_list(const DeviceCtx *__restrict__ c, int *s_cnt /* [kMaxSeedRounds*16+1] */) {
     const int S = c->n_seed;
     const int rounds = (S + 1023) / 1024;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    // pass 1: predicate of seed r*1024 + tid, per-wave counts; the loads of 8 rounds are issued together
     unsigned long long mine = 0;
-    for (int r0 = 0; r0 < rounds; r0 += 8) {
-        float f_md[8], f_vc[8], f_nx[8], f_ny[8], f_nz[8];
-        unsigned char f_fu[8];
+    for (int r0 = 0; r0 < rounds; r0 += 8) { // two byte loads per seed, 8 rounds per batch
+        unsigned char ok[8], fu[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int s = (r0 + q) * 1024 + threadIdx.x;
-            const dsm_seed *sp = &c->seeds[s < S ? s : 0];
-            f_md[q] = sp->mean_depth; f_vc[q] = sp->view_cos;
-            f_nx[q] = sp->norm_x; f_ny[q] = sp->norm_y; f_nz[q] = sp->norm_z;
-            f_fu[q] = sp->fused;
+            ok[q] = c->spawn_ok[s < S ? s : 0];
+            fu[q] = c->fused_flag[s < S ? s : 0];
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int r = r0 + q;
             if (r >= rounds) break;
-            const int s = r * 1024 + threadIdx.x;
-            SeedView sd;
-            sd.size = 0; sd.nx = f_nx[q]; sd.ny = f_ny[q]; sd.nz = f_nz[q];
-            sd.px = sd.py = sd.pz = 0;
-            sd.view_cos = f_vc[q]; sd.mean_depth = f_md[q]; sd.mean_intensity = 0;
-            const bool spawn = s < S && seed_spawns(sd, f_fu[q] != 0);
+            const bool spawn = r * 1024 + (int)threadIdx.x < S && ok[q] && !fu[q];
             if (spawn) mine |= 1ull << r;
             const unsigned long long m = __ballot(spawn);
             if (lane == 0) s_cnt[r * 16 + wv] = __popcll(m);
@@ -873,31 +883,19 @@ __device__ __forceinline__ void tail_new_surfels(const DeviceCtx *__restrict__ c
         if (lane == 0) s_cnt[kMaxSeedRounds * 16] = run;
     }
     __syncthreads();
-    // pass 2: ordered write
     for (int r = 0; r < rounds; r++) {
         const bool spawn = (mine >> r) & 1ull;
         const unsigned long long m = __ballot(spawn);
-        if (!spawn) continue;
-        const int s = r * 1024 + threadIdx.x;
-        const dsm_seed *sp = &c->seeds[s];
-        SeedView sd;
-        sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
-        sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
-        sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
-        const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
-        dsm_surfel o;
-        o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
-        o.size = e.size; o.color = e.color; o.weight = e.weight;
-        o.update_times = e.update_times; o.last_update = e.last_update;
-        c->fresh[s_cnt[r * 16 + wv] + rank_below(m)] = o;
+        if (spawn) c->spawn_idx[s_cnt[r * 16 + wv] + rank_below(m)] = r * 1024 + threadIdx.x;
     }
-    if (threadIdx.x == 0) c->n_new[0] = s_cnt[kMaxSeedRounds * 16];
+    const int K = s_cnt[kMaxSeedRounds * 16];
+    if (threadIdx.x == 0) c->n_new[0] = K;
+    return K;
 }
 
 // ------------------------------------------------------------------------------ hole scan
 // Ascending list of deleted slots (SM.cpp:1078-1083) from the per-wave bitmaps.
-__device__ __forceinline__ void tail_hole_scan(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */) {
-    const int M = c->n_local[0];
+__device__ __forceinline__ int tail_hole_scan(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */, int M) {
     const int n_word = (M + 63) >> 6;
     int run = 0;
     for (int base = 0; base < n_word; base += 1024) {
@@ -918,6 +916,7 @@ __device__ __forceinline__ void tail_hole_scan(const DeviceCtx *__restrict__ c, 
         run += total;
     }
     if (threadIdx.x == 0) c->n_holes[0] = run;
+    return run;
 }
 
 // ------------------------------------------------------------------------------ compaction
@@ -928,7 +927,7 @@ __device__ __forceinline__ void tail_hole_scan(const DeviceCtx *__restrict__ c, 
 //   source index that is itself a remaining hole H[j] (j < i) was overwritten in step j by the
 //   element at M-1-j: follow that chain to a live element.  Targets >= M-r are cut off anyway.
 // Every target is written by exactly one thread and no thread reads a slot another one writes
-// (sources are live slots >= M-r or entries of `fresh`), so the copy is done in place.
+// (sources are live slots >= M-r or prepared new surfels), so the copy is done in place.
 __device__ __forceinline__ bool is_hole(const DeviceCtx *c, int i, int &rank) {
     const unsigned long long m = c->hole_mask[i >> 6];
     const int b = i & 63;
@@ -936,11 +935,11 @@ __device__ __forceinline__ bool is_hole(const DeviceCtx *c, int i, int &rank) {
     return (m >> b) & 1ull;
 }
 
-__device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c) {
-    const int M = c->n_local[0], K = load_coherent(c->n_new), k = load_coherent(c->n_holes);
+__device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c, int M, int K, int k) {
     const int tid = threadIdx.x, nthr = 1024;
     dsm_surfel *local = c->local;
-    const dsm_surfel *fresh = c->fresh;
+    const dsm_surfel *rec = c->spawn_rec;
+    const int32_t *idx = c->spawn_idx; // new surfel j = rec[idx[j]]
     int new_m;
     if (K >= k) {
         new_m = M + (K - k);
@@ -950,19 +949,19 @@ __device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c) {
         }
         for (int j = tid; j < K; j += nthr) {
             const int tgt = j < k ? c->holes[k - 1 - j] : M + (j - k);
-            if (tgt < c->cap) local[tgt] = fresh[j];
+            if (tgt < c->cap) local[tgt] = rec[idx[j]];
         }
     } else {
         const int r = k - K, cut = M - r;
         new_m = cut;
-        for (int j = tid; j < K; j += nthr) local[c->holes[k - 1 - j]] = fresh[j];
+        for (int j = tid; j < K; j += nthr) local[c->holes[k - 1 - j]] = rec[idx[j]];
         for (int i = tid; i < r; i += nthr) {
             const int tgt = c->holes[r - 1 - i];
             if (tgt >= cut) continue;
             int src = M - 1 - i, rank;
             bool hole;
             while ((hole = is_hole(c, src, rank)) && rank < r) src = M - 1 - (r - 1 - rank);
-            local[tgt] = hole ? fresh[k - 1 - rank] : local[src];
+            local[tgt] = hole ? rec[idx[k - 1 - rank]] : local[src];
         }
     }
     if (tid == 0) c->n_local_next[0] = new_m;
@@ -975,14 +974,18 @@ __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, int wi
     const DeviceCtx *__restrict__ c = &ctx;
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
-    tail_new_surfels(c, s_cnt);
+    const int M = c->n_local[0];
+    const int K = tail_spawn_list(c, s_cnt);
+    int k = 0;
+    if (with_compaction) k = tail_hole_scan(c, s_wave, M);
+    __threadfence_block(); // the lists were written by this workgroup (same CU): no device-scope write-back needed
+    __syncthreads();
     if (with_compaction) {
-        tail_hole_scan(c, s_wave);
-        __threadfence_block(); // same workgroup, same CU: no device-scope write-back needed
-        __syncthreads();
-        tail_compact(c);
+        tail_compact(c, M, K, k);
+    } else { // FusionFunctions::fuse_initialize_map hands the new surfels back separately
+        for (int j = threadIdx.x; j < K; j += 1024) c->fresh[j] = c->spawn_rec[c->spawn_idx[j]];
     }
-    __threadfence_block(); // same workgroup, same CU: no device-scope write-back needed
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
         if (with_compaction) c->n_local[0] = c->n_local_next[0];
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_mark_key(const DeviceCtx ctx, int key) 
 __global__ __launch_bounds__(1024) void k_scan_marks(const DeviceCtx ctx) {
     const DeviceCtx *__restrict__ c = &ctx;
     __shared__ int s_wave[17];
-    tail_hole_scan(c, s_wave); // wave_prefix, holes (= marked indices, ascending), n_holes
+    tail_hole_scan(c, s_wave, c->n_local[0]); // wave_prefix, holes (= marked indices, ascending), n_holes
 }
 __global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx ctx, dsm_surfel *__restrict__ out, int cap) {
     const DeviceCtx *__restrict__ c = &ctx;
