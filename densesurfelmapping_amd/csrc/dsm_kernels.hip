@@ -125,9 +125,10 @@ __device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const 
 __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur->dep; }
 
 // ------------------------------------------------------------------------------ init seeds
-__global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx) {
+constexpr int kScanRows = 8;
+__global__ __launch_bounds__(64) void k_init_seeds(const DeviceCtx ctx) {
     const DeviceCtx *__restrict__ c = &ctx;
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.x * 64 + threadIdx.x; // one wave per workgroup: the window scans below are L1-bound, spread them
     if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
     if (s == 0) c->work_count[0] = 0;
     // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
@@ -157,23 +158,23 @@ __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx) {
     }
     // FF.cpp:600-626: a seed whose centre has no depth takes the first depth > 0.01 of its clipped
     // window in row-major order.  Whole image regions (sky) need it at once, so every lane scans its
-    // own window, four rows (16 independent 16-byte loads) per round trip.
+    // own window, eight rows (32 independent 16-byte loads) per round trip.
     if (live && (double)md < 0.01) {
         const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
         const int x_lo = wx0 < 0 ? 0 : wx0, x_hi = wx0 + 2 * kCell > w - 1 ? w - 1 : wx0 + 2 * kCell;
         const int y_lo = wy0 < 0 ? 0 : wy0, y_hi = wy0 + 2 * kCell > h - 1 ? h - 1 : wy0 + 2 * kCell;
         bool found = false;
-        for (int yb = y_lo; yb < y_hi && !found; yb += 4) {
-            float4 v[4][4];
+        for (int yb = y_lo; yb < y_hi && !found; yb += kScanRows) {
+            float4 v[kScanRows][4];
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < kScanRows; r++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int y = yb + r < y_hi ? yb + r : y_hi - 1, x = wx0 + 4 * q;
                     v[r][q] = x >= 0 ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
                 }
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < kScanRows; r++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const float e[4] = {v[r][q].x, v[r][q].y, v[r][q].z, v[r][q].w};
@@ -1151,7 +1152,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
-    hipLaunchStage(k_init_seeds, g_seed_thr, dim3(256), 0, st, hc);
+    hipLaunchStage(k_init_seeds, dim3((S + 63) / 64), dim3(64), 0, st, hc);
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
