@@ -500,10 +500,15 @@ constexpr int kColStride = kWin * kWin + 4;
 // Ordered double sum of one accumulator over the (padded) inlier list.  Blocks of 8 whose residuals are
 // all in the Huber core take the plain path; otherwise the class of each element comes from the
 // wave-uniform masks (noncore / upper / lower), and only Jacobian lanes add the tail term.
+// Scaling by two commutes with every rounding, so the sums are carried halved: a core term is
+// (double)(X*Y) instead of (double)((2*X)*Y), a tail term +-(hr/2)*(double)Y, and the result is doubled
+// once at the end -- bit-identical (no overflow / underflow anywhere near these magnitudes), one multiply
+// less per element.
 __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *yc, int m, const unsigned long long noncore[4],
                                                  const unsigned long long upper[4], const unsigned long long lower[4],
                                                  bool is_j, double hr) {
     double acc = 0.0;
+    const double half_hr = 0.5 * hr;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int lim = m - k * 64 < 64 ? m - k * 64 : 64;
@@ -517,18 +522,20 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
             const unsigned n8 = (unsigned)(noncore[k] >> j) & 0xffu;
             if (n8 == 0) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) acc += (double)(2 * xs[q] * ys[q]);
+                for (int q = 0; q < 8; q++) acc += (double)(xs[q] * ys[q]);
             } else {
                 const unsigned u8 = (unsigned)(upper[k] >> j) & 0xffu, l8 = (unsigned)(lower[k] >> j) & 0xffu;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const int cls = !((n8 >> q) & 1u) ? 0 : ((u8 >> q) & 1u) ? 1 : ((l8 >> q) & 1u) ? 2 : 3;
-                    acc += gn_term(is_j, xs[q], ys[q], cls, hr);
+                    const bool core = !((n8 >> q) & 1u), up = (u8 >> q) & 1u, lo = (l8 >> q) & 1u;
+                    const double t_core = (double)(xs[q] * ys[q]);
+                    const double t_tail = (up ? half_hr : -1 * half_hr) * (double)ys[q];
+                    acc += core ? t_core : ((is_j && (up || lo)) ? t_tail : 0.0);
                 }
             }
         }
     }
-    return acc;
+    return 2.0 * acc;
 }
 
 __global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx ctx) {
