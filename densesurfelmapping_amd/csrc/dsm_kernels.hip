@@ -538,7 +538,7 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
     return 2.0 * acc;
 }
 
-__global__ __launch_bounds__(256) void k_seed_planes(const DeviceCtx ctx) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_seed_planes(const DeviceCtx ctx) {
     const DeviceCtx *__restrict__ c = &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
