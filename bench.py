@@ -341,6 +341,29 @@ def main():
                                       "(kernel alone 26.8 us in profiles/r01_kernel_trace_warp_2M.md); 8 M surfels (704 MB): 5.1 TB/s"}
         ff.close()
 
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # BASELINE configs[3]: live callback, 640x480 RGB-D constants, one frame at a time: host frame in
+        # (H2D), resident map, one hipGraph replay, wait -- the latency the 30 Hz node would see per frame
+        cam_v = synth.VGA_RGBD
+        scene_v = synth.Scene(seed=5, scale=0.12, step=0.05, frames_per_period=30)
+        frames_v = [synth.render(cam_v, scene_v, i)[:2] for i in range(30)]
+        ff = api.FusionFunctions.from_camera(cam_v, device=device, frame_slots=2, surfel_capacity=1 << 20)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        lat = []
+        for t in range(150):
+            img_v, dep_v = frames_v[t % 30]
+            t_l = time.perf_counter()
+            ff.frame_upload(t & 1, img_v, dep_v)
+            ff.fuse_frame_resident(t & 1, t // 5, scene_v.pose(t))
+            ff.synchronize()
+            if t >= 30:
+                lat.append(time.perf_counter() - t_l)
+        lat = np.array(lat) * 1e3
+        out["live_callback_640x480"] = {"latency_ms_p50": round(float(np.median(lat)), 3), "latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
+                                        "map_surfels": ff.map_size(),
+                                        "note": "per frame: pageable host image+depth H2D, fuse (one graph replay), stream sync; RGB-D constant set"}
+        ff.close()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cam, synth.Scene(seed=12345, frames_per_period=period), synth)
 

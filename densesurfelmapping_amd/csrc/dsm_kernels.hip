@@ -4,14 +4,17 @@
 // surfel_fusion/src/surfel_map.cpp of the reference):
 //   k_init_seeds    initialize_seeds_kernel          FF.cpp:577-629
 //   k_assign        update_pixels_kernel             FF.cpp:389-453 (+ calculate_cost 364-387)
-//   k_resolve/k_apply  the sequential `stable` skip rule of FF.cpp:400,445,450 as a fixed point
-//   k_update_seeds  update_seeds_kernel              FF.cpp:468-562
+//   k_resolve       the sequential `stable` skip rule of FF.cpp:400,445,450 as a fixed point
+//   k_update_seeds  update_seeds_kernel              FF.cpp:468-562 (+ the new label image of the sweep)
 //   k_commit_seeds  the early `return` of FF.cpp:516-517 (per worker chunk)
 //   k_seed_planes   calculate_spaces/pixels_norms/sp_depth_norms + get_huber_norm
 //                                                    FF.cpp:644-712, 792-914, 104-188
+//                   and the per-seed part of initialize_surfels, FF.cpp:315-361
 //   k_fuse_surfels  fuse_surfels_kernel              FF.cpp:190-313
-//   k_new_surfels   initialize_surfels               FF.cpp:315-361
-//   k_hole_scan/k_compact  SurfelMap::fuse_map refill + swap-with-last   SM.cpp:1077-1109
+//   k_frame_tail    initialize_surfels (the `fused` test and the ordered list), FF.cpp:315-361;
+//                   SurfelMap::fuse_map refill + swap-with-last, SM.cpp:1077-1109
+//   k_warp          warp_{active,inactive}_surfels_cpu_kernel          SM.cpp:681-789
+//   k_mark_key / k_scan_marks / k_extract_marked   move_add_surfels removal, SM.cpp:1476-1497
 //
 // Build with -ffp-contract=off: results are required to match the CPU reference bit for bit.
 // The work is stencil / gather / ordered reduction -- HBM/L2 bound, no MFMA.
@@ -43,13 +46,6 @@ __device__ __forceinline__ float wave_max(float v) {
     DSM_DPP_MAX(0x142, 0xa); DSM_DPP_MAX(0x143, 0xc);
 #undef DSM_DPP_MAX
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-// value of a double held by lane `src` (compile-time constant), as a wave-uniform scalar
-__device__ __forceinline__ double read_lane_f64(double v, int src) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // order LDS traffic of one wave: a lane's reads after this see every lane's writes before it
 // (the LDS queue of a wave is FIFO; this only stops the compiler from moving accesses across).
