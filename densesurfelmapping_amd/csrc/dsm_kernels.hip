@@ -760,31 +760,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 }
 
 // ------------------------------------------------------------------------------ fuse surfels
-// One lane per surfel, a wave per 64 consecutive surfels (so the deleted-slot bitmap is one ballot).
-// Pure gather: a surfel reads one depth pixel, one label and one seed and rewrites only itself;
-// the single shared write is the idempotent `fused` byte of the seed.
+// One lane per surfel.  Pure gather: a surfel reads one depth pixel, one label and one seed and rewrites
+// only itself; the single shared write is the idempotent `fused` flag of the seed.
+// The 44-byte records are an array of structures: a block moves 256 of them (704 16-byte vectors) through LDS
+// with fully coalesced loads, a lane owns one record at a stride of 11 dwords (odd: conflict-free), and the
+// block is stored back -- again coalesced -- only if one of its surfels changed.  This is the stage that scales
+// with the map: 88 B per live surfel, HBM-bound for large maps.  Deleted slots are reported as one ballot per
+// wave (hole bitmap for the compaction).
+constexpr int kRecDw = sizeof(dsm_surfel) / 4; // 11
+
+// coalesced copy of `cnt` consecutive records between global memory and LDS (records start 16-byte aligned)
+__device__ __forceinline__ void records_to_lds(float *s_rec, const dsm_surfel *src, int cnt, int tid) {
+    const int n_dw = cnt * kRecDw;
+    const float *s1 = reinterpret_cast<const float *>(src);
+    for (int v = tid; v * 4 < n_dw; v += 256) {
+        if (v * 4 + 4 <= n_dw) reinterpret_cast<float4 *>(s_rec)[v] = reinterpret_cast<const float4 *>(s1)[v];
+        else
+            for (int e = v * 4; e < n_dw; e++) s_rec[e] = s1[e];
+    }
+}
+__device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s_rec, int cnt, int tid) {
+    const int n_dw = cnt * kRecDw;
+    float *d1 = reinterpret_cast<float *>(dst);
+    for (int v = tid; v * 4 < n_dw; v += 256) {
+        if (v * 4 + 4 <= n_dw) reinterpret_cast<float4 *>(d1)[v] = reinterpret_cast<const float4 *>(s_rec)[v];
+        else
+            for (int e = v * 4; e < n_dw; e++) d1[e] = s_rec[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx) {
     const DeviceCtx *__restrict__ c = &ctx;
+    __shared__ __attribute__((aligned(16))) float s_rec[256 * kRecDw];
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int M = c->n_local[0];
-    const int n_wave = (M + 63) >> 6;
-    const int lane = lane_id();
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     FuseConst fc;
     fc.k = c->k; fc.far_d = c->far_d; fc.near_d = c->near_d;
     fc.baseline = c->baseline; fc.disp_err = c->disp_err; fc.min_tol = c->min_tol;
     fc.w = c->w; fc.h = c->h;
     const int ref_idx = fp.ref_idx;
-    const int waves_total = (gridDim.x * 256) >> 6;
-    for (int wv = (blockIdx.x * 256 + threadIdx.x) >> 6; wv < n_wave; wv += waves_total) {
-        const int i = wv * 64 + lane;
-        bool hole = false;
-        if (i < M) {
-            const dsm_surfel raw = c->local[i];
+    for (int base = blockIdx.x * 256; base < M; base += gridDim.x * 256) {
+        const int cnt = M - base < 256 ? M - base : 256;
+        records_to_lds(s_rec, c->local + base, cnt, tid);
+        __syncthreads();
+        bool hole = false, changed = false;
+        if (tid < cnt) {
+            float *r = s_rec + tid * kRecDw;
             Surfel e;
-            e.px = raw.px; e.py = raw.py; e.pz = raw.pz; e.nx = raw.nx; e.ny = raw.ny; e.nz = raw.nz;
-            e.size = raw.size; e.color = raw.color; e.weight = raw.weight;
-            e.update_times = raw.update_times; e.last_update = raw.last_update;
+            e.px = r[0]; e.py = r[1]; e.pz = r[2]; e.nx = r[3]; e.ny = r[4]; e.nz = r[5];
+            e.size = r[6]; e.color = r[7]; e.weight = r[8];
+            e.update_times = __float_as_int(r[9]); e.last_update = __float_as_int(r[10]);
             int ui, vi;
             float pc[3], nc[3];
             FuseOutcome oc = fuse_project(fc, ref_idx, fp.inv, e, ui, vi, pc, nc);
@@ -800,18 +827,20 @@ __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx) {
                 if (oc == kFuseFused) { c->seeds[sidx].fused = 1; c->fused_flag[sidx] = 1; }
             }
             if (oc == kFuseDeleted) {
-                c->local[i].update_times = 0;
+                r[9] = __int_as_float(0);
+                changed = true;
             } else if (oc == kFuseFused) {
-                dsm_surfel o;
-                o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
-                o.size = e.size; o.color = e.color; o.weight = e.weight;
-                o.update_times = e.update_times; o.last_update = e.last_update;
-                c->local[i] = o;
+                r[0] = e.px; r[1] = e.py; r[2] = e.pz; r[3] = e.nx; r[4] = e.ny; r[5] = e.nz;
+                r[6] = e.size; r[7] = e.color; r[8] = e.weight;
+                r[9] = __int_as_float(e.update_times); r[10] = __int_as_float(e.last_update);
+                changed = true;
             }
             hole = e.update_times == 0;
         }
         const unsigned long long m = __ballot(hole);
-        if (lane == 0) c->hole_mask[wv] = m;
+        if (lane == 0 && base + wv * 64 < M) c->hole_mask[(base >> 6) + wv] = m;
+        if (__syncthreads_or(changed ? 1 : 0)) records_from_lds(c->local + base, s_rec, cnt, tid);
+        __syncthreads();
     }
 }
 

@@ -139,6 +139,26 @@ def test_api_errors_are_reported(mods):
     assert ei.value.code == -4
 
 
+def test_quiet_scene_many_stable_seeds(mods):
+    """Low-noise, flat-albedo scene: most superpixels stop moving after the first sweep, so most pixels sit
+    between stable seeds -- the regime where the scan-order rule (worklist fixed point) decides the labels."""
+    api, synth, ob = mods
+    cam = synth.VGA_DRIVE
+    scene = synth.Scene(seed=3, intensity_noise=1.0, checker=4.0, depth_noise=0.0002, hole_fraction=0.002)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
+    orc = ob.PortOracle(cam)
+    lg = np.zeros(0, api.SURFEL_DTYPE)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    stable_seen = 0
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, 6):
+        lg, kg = ff.fuse_map(ref, img, dep, pose, lg)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert kg == ko
+        _compare_frame(f"quiet frame {t}", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+        stable_seen = max(stable_seen, int(orc.seeds()["stable"].sum()))
+    assert stable_seen > ff.n_seed // 3, "the scene no longer produces many stable seeds"
+
+
 def test_batched_replay_matches_stepwise(mods):
     """dsm_replay_enqueue of a whole subsequence (no host sync in between) == frame-by-frame."""
     api, synth, ob = mods
