@@ -44,6 +44,8 @@ ABI_SYMBOLS = (
     "dsm_fuse_initialize_map", "dsm_fuse_map",
     "dsm_map_upload", "dsm_map_size", "dsm_map_download", "dsm_map_copy_to_device",
     "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
+    "dsm_store_deactivate", "dsm_store_activate", "dsm_store_erase", "dsm_store_warp", "dsm_store_size",
+    "dsm_store_download",
     "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps",
@@ -105,6 +107,12 @@ def load_library():
     lib.dsm_warp_grouped_device.argtypes = [_vp, _vp, C.c_int32, _vp, _vp]
     lib.dsm_map_extract.argtypes = [_vp, C.c_int32, _vp, C.c_int32, _vp]
     lib.dsm_map_append.argtypes = [_vp, _vp, C.c_int32]
+    lib.dsm_store_deactivate.argtypes = [_vp, C.c_int32, _vp, _vp]
+    lib.dsm_store_activate.argtypes = [_vp, C.c_int32, C.c_int32]
+    lib.dsm_store_erase.argtypes = [_vp, C.c_int32, C.c_int32]
+    lib.dsm_store_warp.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
+    lib.dsm_store_size.argtypes = [_vp, _vp]
+    lib.dsm_store_download.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp]
     lib.dsm_frame_upload.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
     lib.dsm_frame_upload_device.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
     lib.dsm_fuse_frame_resident.argtypes = [_vp, C.c_int, C.c_int, _vp]

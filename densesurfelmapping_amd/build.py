@@ -17,8 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libdsm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["dsm_kernels.hip", "dsm_api.hip"]
-HEADERS = ["dsm_math.h", "dsm_device.h", os.path.join("..", "..", "include", "dsm.h")]
+SOURCES = ["dsm_kernels.hip", "dsm_api.hip", "dsm_surfel_map.cpp"]
+HEADERS = ["dsm_math.h", "dsm_device.h", os.path.join("..", "..", "include", "dsm.h"),
+           os.path.join("..", "..", "include", "dsm_surfel_map.h")]
 
 
 def _hipcc() -> str:

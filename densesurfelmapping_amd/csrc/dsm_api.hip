@@ -53,6 +53,13 @@ struct dsm_handle {
     bool map_valid = false;
     hipEvent_t ev[kNumStages + 2];
     bool have_events = false;
+    // inactive store: surfels of keyframes outside the local window, back to back in HBM, with the XYZI
+    // shadow the reference publishes and saves (`inactive_pointcloud`)
+    dsm_surfel *d_store = nullptr;
+    float4 *d_cloud = nullptr;
+    void *d_store_tmp = nullptr;
+    size_t store_tmp_bytes = 0;
+    int store_cap = 0, store_n = 0;
     std::string err;
 };
 
@@ -457,6 +464,9 @@ void dsm_destroy(dsm_handle *h) {
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
     for (void *p : h->allocs) (void)hipFree(p);
+    if (h->d_store) (void)hipFree(h->d_store);
+    if (h->d_cloud) (void)hipFree(h->d_cloud);
+    if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
     if (h->h_params) (void)hipHostFree(h->h_params);
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -638,6 +648,142 @@ int dsm_map_append(dsm_handle *h, const dsm_surfel *surfels, int32_t n) {
     hipError_t e = launch_append_count(h->hc, n, h->stream);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "append: %s", hipGetErrorString(e));
     h->map_upper = m + n;
+    return DSM_OK;
+}
+
+// ------------------------------------------------------------------ inactive store
+namespace {
+int store_reserve(dsm_handle *h, int need) {
+    if (need <= h->store_cap) return DSM_OK;
+    int cap = h->store_cap ? h->store_cap : (1 << 18);
+    while (cap < need) {
+        if (cap > (1 << 30)) return fail(h, DSM_E_CAPACITY, "inactive store of %d surfels", need);
+        cap *= 2;
+    }
+    dsm_surfel *ns = nullptr;
+    float4 *nc = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&ns, sizeof(dsm_surfel) * (size_t)cap + 256));
+    hipError_t e = hipMalloc((void **)&nc, sizeof(float4) * (size_t)cap);
+    if (e != hipSuccess) { (void)hipFree(ns); return fail(h, DSM_E_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (h->store_n) {
+        e = hipMemcpyAsync(ns, h->d_store, sizeof(dsm_surfel) * (size_t)h->store_n, hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nc, h->d_cloud, sizeof(float4) * (size_t)h->store_n, hipMemcpyDeviceToDevice, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { (void)hipFree(ns); (void)hipFree(nc); return fail(h, DSM_E_HIP, "store growth: %s", hipGetErrorString(e)); }
+    if (h->d_store) (void)hipFree(h->d_store);
+    if (h->d_cloud) (void)hipFree(h->d_cloud);
+    h->d_store = ns;
+    h->d_cloud = nc;
+    h->store_cap = cap;
+    return DSM_OK;
+}
+} // namespace
+
+int dsm_store_size(dsm_handle *h, int32_t *n) {
+    if (!h || !n) return DSM_E_INVALID;
+    *n = h->store_n;
+    return DSM_OK;
+}
+
+int dsm_store_deactivate(dsm_handle *h, int32_t key, int32_t *begin, int32_t *n) {
+    if (!h || !begin || !n) return DSM_E_INVALID;
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    hipError_t e = launch_mark(h->hc, key, m, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h->h_scalars[3], h->hc.n_holes, 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "deactivate: %s", hipGetErrorString(e));
+    const int k = h->h_scalars[3];
+    if ((rc = store_reserve(h, h->store_n + k))) return rc;
+    if (k) {
+        e = launch_extract_marked(h->hc, h->d_store + h->store_n, k, h->d_cloud + h->store_n, h->stream);
+        if (e != hipSuccess) return fail(h, DSM_E_HIP, "deactivate: %s", hipGetErrorString(e));
+    }
+    *begin = h->store_n;
+    *n = k;
+    h->store_n += k;
+    return DSM_OK;
+}
+
+int dsm_store_activate(dsm_handle *h, int32_t begin, int32_t n) {
+    if (!h) return DSM_E_INVALID;
+    if (begin < 0 || n < 0 || begin + n > h->store_n) return fail(h, DSM_E_INVALID, "store range [%d,+%d) outside [0,%d)", begin, n, h->store_n);
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    if ((rc = sync_and_fetch_counts(h))) return rc;
+    const int m = h->h_scalars[0];
+    if (m + n > h->hc.cap) return fail(h, DSM_E_CAPACITY, "%d + %d surfels exceed the handle's capacity %d", m, n, h->hc.cap);
+    if (n) HIP_TRY(h, hipMemcpyAsync(h->hc.local + m, h->d_store + begin, sizeof(dsm_surfel) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    hipError_t e = launch_append_count(h->hc, n, h->stream);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "activate: %s", hipGetErrorString(e));
+    h->map_upper = m + n;
+    return DSM_OK;
+}
+
+int dsm_store_erase(dsm_handle *h, int32_t begin, int32_t n) {
+    if (!h) return DSM_E_INVALID;
+    if (begin < 0 || n < 0 || begin + n > h->store_n) return fail(h, DSM_E_INVALID, "store range [%d,+%d) outside [0,%d)", begin, n, h->store_n);
+    int rc = bind_device(h);
+    if (rc) return rc;
+    const int tail = h->store_n - (begin + n);
+    if (n && tail) { // the tail moves down through a scratch copy (the ranges overlap)
+        const size_t need = sizeof(dsm_surfel) * (size_t)tail;
+        if (need > h->store_tmp_bytes) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
+            h->d_store_tmp = nullptr;
+            h->store_tmp_bytes = 0;
+            HIP_TRY(h, hipMalloc(&h->d_store_tmp, need * 2));
+            h->store_tmp_bytes = need * 2;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_store_tmp, h->d_store + begin + n, need, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_store + begin, h->d_store_tmp, need, hipMemcpyDeviceToDevice, h->stream));
+        const size_t need_c = sizeof(float4) * (size_t)tail;
+        HIP_TRY(h, hipMemcpyAsync(h->d_store_tmp, h->d_cloud + begin + n, need_c, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_cloud + begin, h->d_store_tmp, need_c, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->store_n -= n;
+    return DSM_OK;
+}
+
+int dsm_store_warp(dsm_handle *h, int32_t n_groups, const int32_t *offsets, const float *mats16, const uint8_t *changed) {
+    if (!h) return DSM_E_INVALID;
+    if (n_groups < 0 || (n_groups > 0 && (!offsets || !mats16 || !changed))) return fail(h, DSM_E_INVALID, "null/negative argument");
+    if (n_groups == 0) return DSM_OK;
+    if (offsets[0] != 0 || offsets[n_groups] != h->store_n) return fail(h, DSM_E_INVALID, "offsets must tile the store [0,%d)", h->store_n);
+    for (int g = 0; g < n_groups; g++)
+        if (offsets[g] > offsets[g + 1]) return fail(h, DSM_E_INVALID, "offsets must ascend");
+    if (h->store_n == 0) return DSM_OK;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    const size_t b_m = sizeof(float) * 16 * (size_t)n_groups, b_o = sizeof(int32_t) * ((size_t)n_groups + 1);
+    char *d = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d, b_m + b_o + (size_t)n_groups));
+    hipError_t e = hipMemcpyAsync(d, mats16, b_m, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + b_m, offsets, b_o, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + b_m + b_o, changed, (size_t)n_groups, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess)
+        e = launch_warp(h->d_store, nullptr, h->store_n, (const float *)d, (const int32_t *)(d + b_m), n_groups, h->store_n, h->stream,
+                        (const uint8_t *)(d + b_m + b_o), h->d_cloud);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the host arrays may be reused, the scratch freed
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "store warp: %s", hipGetErrorString(e));
+    return DSM_OK;
+}
+
+int dsm_store_download(dsm_handle *h, int32_t begin, int32_t n, dsm_surfel *surfels_out, float *xyzi_out) {
+    if (!h) return DSM_E_INVALID;
+    if (begin < 0 || n < 0 || begin + n > h->store_n) return fail(h, DSM_E_INVALID, "store range [%d,+%d) outside [0,%d)", begin, n, h->store_n);
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (n && surfels_out) HIP_TRY(h, hipMemcpy(surfels_out, h->d_store + begin, sizeof(dsm_surfel) * (size_t)n, hipMemcpyDeviceToHost));
+    if (n && xyzi_out) HIP_TRY(h, hipMemcpy(xyzi_out, h->d_cloud + begin, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
     return DSM_OK;
 }
 

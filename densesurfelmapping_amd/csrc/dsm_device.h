@@ -100,7 +100,10 @@ hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_com
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);
 
 hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
-                       const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st);
+                       const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st,
+                       const uint8_t *d_group_on = nullptr, float4 *d_cloud = nullptr);
+hipError_t launch_mark(const DeviceCtx &ctx, int key, int n_upper, hipStream_t st);
+hipError_t launch_extract_marked(const DeviceCtx &ctx, dsm_surfel *out, int cap, float4 *cloud_out, hipStream_t st);
 hipError_t launch_extract(const DeviceCtx &ctx, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st);
 hipError_t launch_append_count(const DeviceCtx &ctx, int n, hipStream_t st);
 

@@ -1032,14 +1032,34 @@ __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, int wi
 // A block moves 256 records = 704 16-byte vectors through LDS with fully coalesced loads and stores; a
 // lane then owns one record at stride 11 dwords (odd: conflict-free).  group_offsets == nullptr: one
 // matrix for all (the reference's active-map case); otherwise record i uses the matrix of its group.
+//
+// Inactive store (dsm_store_warp): group_on[g] == 0 leaves group g untouched (SM.cpp:691-695: poses whose
+// cam_pose already equals loop_pose are skipped), and `cloud` is the XYZI shadow of the store
+// (`inactive_pointcloud`): SM.cpp:742 copies [&front, &back) of the warped points, i.e. every point of a
+// keyframe's patch except its last one, which keeps its stale position.
+__device__ __forceinline__ int warp_group_of(const int32_t *__restrict__ group_offsets, int n_groups, int i) {
+    int lo = 0, hi = n_groups; // last g with offsets[g] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (group_offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, const int32_t *__restrict__ n_ptr,
                                               int32_t n_fixed, const float *__restrict__ mats,
-                                              const int32_t *__restrict__ group_offsets, int32_t n_groups) {
+                                              const int32_t *__restrict__ group_offsets, int32_t n_groups,
+                                              const uint8_t *__restrict__ group_on, float4 *__restrict__ cloud) {
     __shared__ __attribute__((aligned(16))) float s_rec[256 * 11];
     const int n = n_ptr ? n_ptr[0] : n_fixed;
     const int tid = threadIdx.x;
     for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
         const int cnt = n - base < 256 ? n - base : 256;
+        if (group_on) { // block-uniform: skip blocks that only hold untouched groups
+            const int g0 = warp_group_of(group_offsets, n_groups, base), g1 = warp_group_of(group_offsets, n_groups, base + cnt - 1);
+            bool any = false;
+            for (int g = g0; g <= g1; g++) any |= group_on[g] != 0;
+            if (!any) continue;
+        }
         const int n_vec = (cnt * 11 + 3) >> 2; // 44-byte records: a block of 256 starts 16-byte aligned
         const float4 *src = reinterpret_cast<const float4 *>(surfels + base);
         float4 *dst = reinterpret_cast<float4 *>(surfels + base);
@@ -1055,22 +1075,23 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
         __syncthreads();
         if (tid < cnt) {
             const float *m = mats;
+            bool on = true;
+            int g = 0;
             if (group_offsets) {
-                int lo = 0, hi = n_groups; // last g with offsets[g] <= i
-                const int i = base + tid;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (group_offsets[mid] <= i) lo = mid; else hi = mid;
-                }
-                m = mats + 16 * lo;
+                g = warp_group_of(group_offsets, n_groups, base + tid);
+                m = mats + 16 * g;
+                if (group_on) on = group_on[g] != 0;
             }
-            float *r = s_rec + tid * 11;
-            const float p[3] = {r[0], r[1], r[2]}, v[3] = {r[3], r[4], r[5]};
-            float o[3], w[3];
-            xform_point(m, p, o);
-            xform_dir(m, v, w);
-            r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
-            r[3] = w[0]; r[4] = w[1]; r[5] = w[2];
+            if (on) {
+                float *r = s_rec + tid * 11;
+                const float p[3] = {r[0], r[1], r[2]}, v[3] = {r[3], r[4], r[5]};
+                float o[3], w[3];
+                xform_point(m, p, o);
+                xform_dir(m, v, w);
+                r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+                r[3] = w[0]; r[4] = w[1]; r[5] = w[2];
+                if (cloud && base + tid != group_offsets[g + 1] - 1) cloud[base + tid] = make_float4(o[0], o[1], o[2], r[7]);
+            }
         }
         __syncthreads();
         for (int v = tid; v < n_vec; v += 256) {
@@ -1105,36 +1126,50 @@ __global__ __launch_bounds__(1024) void k_scan_marks(const DeviceCtx ctx) {
     __shared__ int s_wave[17];
     tail_hole_scan(c, s_wave, c->n_local[0]); // wave_prefix, holes (= marked indices, ascending), n_holes
 }
-__global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx ctx, dsm_surfel *__restrict__ out, int cap) {
+__global__ __launch_bounds__(256) void k_extract_marked(const DeviceCtx ctx, dsm_surfel *__restrict__ out, int cap,
+                                                        float4 *__restrict__ cloud_out) {
     const DeviceCtx *__restrict__ c = &ctx;
     const int k = c->n_holes[0];
     for (int j = blockIdx.x * 256 + threadIdx.x; j < k && j < cap; j += gridDim.x * 256) {
         const int i = c->holes[j];
-        out[j] = c->local[i];
+        const dsm_surfel e = c->local[i];
+        out[j] = e;
+        if (cloud_out) cloud_out[j] = make_float4(e.px, e.py, e.pz, e.color); // SM.cpp:1483-1488
         c->local[i].update_times = 0;
     }
 }
+// count only (sizing pass of dsm_store_deactivate): k_mark_key + k_scan_marks leave the count in n_holes
 __global__ void k_append(const DeviceCtx ctx, int n) {
     const DeviceCtx *__restrict__ c = &ctx;
     if (threadIdx.x == 0 && blockIdx.x == 0) c->n_local[0] = c->n_local[0] + n;
 }
 
 hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
-                       const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st) {
+                       const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st, const uint8_t *d_group_on,
+                       float4 *d_cloud) {
     int blocks = (n_upper + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, d_offsets, n_groups);
+    hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, d_offsets, n_groups,
+                       d_group_on, d_cloud);
     return hipGetLastError();
 }
-hipError_t launch_extract(const DeviceCtx &d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st) {
+hipError_t launch_mark(const DeviceCtx &d, int key, int n_upper, hipStream_t st) {
     int blocks = (n_upper + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_mark_key, dim3(blocks), dim3(256), 0, st, d, key);
     hipLaunchKernelGGL(k_scan_marks, dim3(1), dim3(1024), 0, st, d);
-    hipLaunchKernelGGL(k_extract_marked, dim3(64), dim3(256), 0, st, d, out, cap);
     return hipGetLastError();
+}
+hipError_t launch_extract_marked(const DeviceCtx &d, dsm_surfel *out, int cap, float4 *cloud_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_extract_marked, dim3(64), dim3(256), 0, st, d, out, cap, cloud_out);
+    return hipGetLastError();
+}
+hipError_t launch_extract(const DeviceCtx &d, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st) {
+    hipError_t e = launch_mark(d, key, n_upper, st);
+    if (e != hipSuccess) return e;
+    return launch_extract_marked(d, out, cap, nullptr, st);
 }
 hipError_t launch_append_count(const DeviceCtx &d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_append, dim3(1), dim3(64), 0, st, d, n);

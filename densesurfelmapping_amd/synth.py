@@ -188,3 +188,99 @@ def sequence(cam: Camera, scene: Scene, n_frames: int, start: int = 0):
             cache[tl] = render(cam, scene, tl)[:2]
         image, depth = cache[tl]
         yield t, image, depth, scene.pose(t), (t - start) // 5
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Node-level message stream: what kitti_publisher (image, depth) and the modified ORB-SLAM2 (loop_stamps,
+# loop_path, this_pose) send to the surfel_fusion node (ros_node.cpp:24-32), as plain tuples.
+
+NODE_CAM = Camera(320, 104, 185.0, 185.0, 159.5, 51.5)   # small frames for node-level tests (8 | W, 8 | H)
+
+
+def _rot_to_quat(R: np.ndarray) -> np.ndarray:
+    """x, y, z, w of a proper rotation matrix (any correct conversion will do: both sides get the same bytes)."""
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2.0
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax([R[0, 0], R[1, 1], R[2, 2]]))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2.0
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[3] = (R[k, j] - R[j, k]) / s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def pose7(m: np.ndarray) -> np.ndarray:
+    """4x4 cam->world -> geometry_msgs/Pose as [px, py, pz, qx, qy, qz, qw] (float64)."""
+    m = np.asarray(m, dtype=np.float64)
+    return np.concatenate([m[:3, 3], _rot_to_quat(m[:3, :3])])
+
+
+def _drift(t: int, rate: float) -> np.ndarray:
+    """Accumulated odometry drift after t frames: a small yaw about the vertical axis plus a lateral offset."""
+    a = np.deg2rad(0.02) * rate * t
+    d = np.eye(4)
+    d[0, 0], d[0, 2], d[2, 0], d[2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+    d[0, 3] = 0.004 * rate * t
+    return d
+
+
+def node_messages(cam: Camera, scene: Scene, n_frames: int, lap: int = 40, keyframe_every: int = 5, drift_rate: float = 1.0,
+                  path_lag: int = 0, pose_first=(), drop_pose=(), extra_loops=None):
+    """Yield the node's input messages for ``n_frames`` frames of a circuit of ``lap`` frames.
+
+    The camera drives the scene's trajectory and jumps back to the start after every ``lap`` frames (a closed
+    circuit).  During the first lap the SLAM poses carry a slowly growing drift; when the camera is back at the
+    start, the frame is a keyframe with a loop edge to keyframe 0 and from then on the loop path holds the
+    drift-free poses, so every keyframe of the first lap is corrected (surfel_map.cpp:235-280).
+
+    Events, in publication order:
+      ("image", (sec, nsec), uint8[H,W]) / ("depth", (sec, nsec), float32[H,W])
+      ("orb", (sec, nsec), loop_values float32[2k], loop_path float64[n,7], this_pose float64[7], covariance float64[36])
+    ``pose_first``: frames whose orb message precedes their images; ``drop_pose``: frames without orb message
+    (never a keyframe); ``path_lag``: the loop path misses the newest ``path_lag`` keyframes (:254-270);
+    ``extra_loops``: {frame: [(kf_a, kf_b), ...]} additional loop edges announced at that frame.
+    """
+    extra_loops = extra_loops or {}
+    frames = {}
+    true_kf, est_kf = [], []       # per keyframe: drift-free and estimated cam->world
+    loops = []
+    closed = False
+    for t in range(n_frames):
+        tl = t % lap
+        if tl not in frames:
+            frames[tl] = render(cam, scene, tl)[:2]
+        image, depth = frames[tl]
+        stamp = (1000 + t // 10, (t % 10) * 100000000)
+        true_pose = scene.pose(tl).astype(np.float64)
+        is_kf = t % keyframe_every == 0
+        if t >= lap and not closed and is_kf:
+            closed = True
+            loops.append((len(true_kf), 0))
+        est_pose = true_pose if closed else _drift(t, drift_rate) @ true_pose
+        ref_kf = max(len(true_kf) - 1, 0)
+        if is_kf:
+            true_kf.append(true_pose)
+            est_kf.append(est_pose)
+        loops.extend(extra_loops.get(t, []))
+        path_src = true_kf if closed else est_kf
+        n_path = max(1, len(path_src) - path_lag)
+        path = np.stack([pose7(p) for p in path_src[:n_path]])
+        cov = np.zeros(36)
+        cov[0] = 1.0 if is_kf else 0.0
+        cov[1] = float(ref_kf)
+        orb = ("orb", stamp, np.array([v for ab in loops for v in ab], dtype=np.float32), path, pose7(est_pose), cov)
+        img = [("image", stamp, image), ("depth", stamp, depth)]
+        if t in drop_pose and not is_kf:
+            yield from img
+        elif t in pose_first:
+            yield orb
+            yield from img
+        else:
+            yield from img
+            yield orb

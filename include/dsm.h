@@ -145,6 +145,29 @@ int dsm_map_extract(dsm_handle *h, int32_t key, dsm_surfel *out, int32_t cap, in
 /* move_add_surfels, insertion half (surfel_map.cpp:1583-1590): append to the resident map. */
 int dsm_map_append(dsm_handle *h, const dsm_surfel *surfels, int32_t n);
 
+/* ---- inactive store: the surfels of keyframes that left the local window stay in HBM, back to back in
+ * deactivation order, each with the XYZI point the reference keeps in `inactive_pointcloud`
+ * (surfel_map.cpp:1476-1497 fills poses_database[i].attached_surfels and inactive_pointcloud; here both are
+ * one device arena indexed like inactive_pointcloud).  The segment table (which keyframe owns [begin,
+ * begin+n)) is host state of the caller -- include/dsm_surfel_map.h keeps it as the reference does
+ * (points_begin_index / points_pose_index / pointcloud_pose_index). ---- */
+
+/* surfel_map.cpp:1476-1497: move the live resident surfels with last_update == key, in index order, to the
+ * end of the store (slots marked deleted in the map).  Returns the segment.  Synchronises. */
+int dsm_store_deactivate(dsm_handle *h, int32_t key, int32_t *begin, int32_t *n);
+/* surfel_map.cpp:1583-1590: append store[begin, begin+n) to the resident map (the store is not changed). */
+int dsm_store_activate(dsm_handle *h, int32_t begin, int32_t n);
+/* surfel_map.cpp:1551-1553 (`inactive_pointcloud->erase`): remove [begin, begin+n); the tail moves down. */
+int dsm_store_erase(dsm_handle *h, int32_t begin, int32_t n);
+/* surfel_map.cpp:681-748 for every keyframe at once: offsets[n_groups+1] tile the store, group g is warped
+ * by mats16[16 g ..] (column-major float) when changed[g] != 0 and left alone otherwise; the XYZI shadow is
+ * refreshed for all points of a warped group except its last (surfel_map.cpp:742).  Synchronises. */
+int dsm_store_warp(dsm_handle *h, int32_t n_groups, const int32_t *offsets, const float *mats16,
+                   const uint8_t *changed);
+int dsm_store_size(dsm_handle *h, int32_t *n);
+/* either output may be NULL; xyzi_out receives 4 floats per point (x, y, z, intensity).  Synchronises. */
+int dsm_store_download(dsm_handle *h, int32_t begin, int32_t n, dsm_surfel *surfels_out, float *xyzi_out);
+
 int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
                      size_t depth_step);
 /* same, sources already in device memory */

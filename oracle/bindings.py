@@ -190,3 +190,98 @@ class PortOracle(_Base):
         super().__init__(lib, cam)
         if cam.rgbd:
             lib.dsmo_set_constants(self.h_, 0.05, 0.08, 1.0, 0.05)  # fusion_functions.h:17-21
+
+
+class RefSurfelMap:
+    """oracle/_ref/libdsm_ref_map.so: the reference's node class (surfel_map.cpp + fusion_functions.cpp compiled
+    in place, oracle/ref_map_driver.cpp) behind the same message-level interface as
+    densesurfelmapping_amd.surfel_map.SurfelMap."""
+
+    def __init__(self, cam, drift_free_poses=10):
+        lib = C.CDLL(ref_lib_path("map"))
+        lib.refmap_create.restype = _vp
+        lib.refmap_create.argtypes = [C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_int]
+        lib.refmap_destroy.argtypes = [_vp]
+        lib.refmap_image_input.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_size_t, _vp]
+        lib.refmap_depth_input.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_size_t, _vp]
+        lib.refmap_orb_results_input.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, C.c_int, _vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp]
+        for name in ("pending_poses", "local_count", "pose_count", "cloud_count"):
+            getattr(lib, "refmap_" + name).argtypes = [_vp]
+        lib.refmap_get_local.argtypes = [_vp, _vp]
+        lib.refmap_get_pose.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+        lib.refmap_get_links.argtypes = [_vp, C.c_int, _vp, C.c_int]
+        lib.refmap_get_attached.argtypes = [_vp, C.c_int, _vp]
+        lib.refmap_get_cloud.argtypes = [_vp, _vp]
+        lib.refmap_save_cloud.argtypes = [_vp, C.c_char_p]
+        lib.refmap_save_mesh.argtypes = [_vp, C.c_char_p]
+        self._lib = lib
+        self.cam = cam
+        self._h = lib.refmap_create(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near, drift_free_poses)
+        self.frames_fused = 0
+
+    def close(self):
+        if self._h:
+            self._lib.refmap_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, event):
+        before = self._lib.refmap_pending_poses(self._h)
+        if event[0] == "image":
+            img = np.ascontiguousarray(event[2], dtype=np.uint8)
+            self._lib.refmap_image_input(self._h, event[1][0], event[1][1], img.shape[1], img.shape[0], img.strides[0], _ptr(img))
+        elif event[0] == "depth":
+            d = np.ascontiguousarray(event[2], dtype=np.float32)
+            self._lib.refmap_depth_input(self._h, event[1][0], event[1][1], d.shape[1], d.shape[0], d.strides[0], _ptr(d))
+        else:
+            lv = np.ascontiguousarray(event[2], dtype=np.float32)
+            lp = np.ascontiguousarray(event[3], dtype=np.float64).reshape(-1, 7)
+            tp = np.ascontiguousarray(event[4], dtype=np.float64)
+            cov = np.ascontiguousarray(event[5], dtype=np.float64)
+            self._lib.refmap_orb_results_input(self._h, event[1][0], event[1][1], _ptr(lv), lv.size, _ptr(lp), lp.shape[0],
+                                               event[1][0], event[1][1], _ptr(tp), _ptr(cov))
+            before += 1
+        self.frames_fused += before - self._lib.refmap_pending_poses(self._h)  # a pose leaves the buffer when it is fused
+
+    @property
+    def pose_count(self):
+        return self._lib.refmap_pose_count(self._h)
+
+    def local_surfels(self):
+        n = self._lib.refmap_local_count(self._h)
+        out = np.zeros(max(n, 1), dtype=SURFEL_DTYPE)
+        self._lib.refmap_get_local(self._h, _ptr(out))
+        return out[:n]
+
+    def pose(self, i):
+        cam, loop = np.zeros(7), np.zeros(7)
+        n_att, begin, is_local = C.c_int(), C.c_int(), C.c_int()
+        self._lib.refmap_get_pose(self._h, i, _ptr(cam), _ptr(loop), C.byref(n_att), C.byref(begin), C.byref(is_local))
+        links = np.zeros(4096, dtype=np.int32)
+        n = self._lib.refmap_get_links(self._h, i, _ptr(links), links.size)
+        return {"cam_pose": cam, "loop_pose": loop, "n_attached": n_att.value, "points_begin_index": begin.value,
+                "is_local": bool(is_local.value), "links": links[:n].tolist()}
+
+    def attached_surfels(self, i):
+        n = self.pose(i)["n_attached"]
+        out = np.zeros(max(n, 1), dtype=SURFEL_DTYPE)
+        self._lib.refmap_get_attached(self._h, i, _ptr(out))
+        return out[:n]
+
+    def inactive_cloud(self):
+        n = self._lib.refmap_cloud_count(self._h)
+        out = np.zeros((max(n, 1), 4), dtype=np.float32)
+        self._lib.refmap_get_cloud(self._h, _ptr(out))
+        return out[:n]
+
+    def save_cloud(self, path):
+        if self._lib.refmap_save_cloud(self._h, path.encode()) != 0:
+            raise RuntimeError("pcl::PCDWriter: Input point cloud has no data!")
+
+    def save_mesh(self, path):
+        self._lib.refmap_save_mesh(self._h, path.encode())

@@ -1,0 +1,7 @@
+// Oracle shim (test infrastructure)
+#pragma once
+#include "geometry_msgs/Pose.h"
+namespace nav_msgs {
+struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; };
+typedef boost::shared_ptr<const Path> PathConstPtr;
+}

@@ -54,6 +54,37 @@ inline int waitKey(int) { return 0; }
 // uchar is used unqualified inside cv::Mat::at<uchar> call sites (FF.cpp:402).
 using cv::uchar;
 
+#ifdef DSM_ORACLE_DEFERRED_THREADS
+// Deterministic schedule for the node (surfel_map.cpp): a std::thread stand-in that runs its callable
+// when it is joined.  SurfelMap::warp_surfels starts ten workers over the keyframes, then reads
+// poses_database[local].cam_pose on the main thread, then starts ten more and joins all twenty
+// (SM.cpp:791-824); the first ten overwrite cam_pose (SM.cpp:698-702,741), so running them inside the
+// constructor would change what the main thread reads.  Run-at-join is the schedule in which the main
+// thread gets there first; workers then execute in index order.  For fusion_functions.cpp (create all,
+// then join all in order) it is the same index-order schedule as DSM_ORACLE_SERIAL_THREADS.
+#include <thread>
+#include <functional>
+namespace std {
+class dsm_serial_thread {
+public:
+    dsm_serial_thread() : pending_(false) {}
+    template <class F, class... A> explicit dsm_serial_thread(F &&f, A &&...a)
+        : f_(std::bind(std::forward<F>(f), std::forward<A>(a)...)), pending_(true) {}
+    dsm_serial_thread(dsm_serial_thread &&o) : f_(std::move(o.f_)), pending_(o.pending_) { o.pending_ = false; }
+    dsm_serial_thread(const dsm_serial_thread &) = delete;
+    bool joinable() const { return pending_; }
+    void join() {
+        pending_ = false;
+        f_();
+    }
+private:
+    std::function<void()> f_;
+    bool pending_;
+};
+}  // namespace std
+#define thread dsm_serial_thread
+#endif
+
 #ifdef DSM_ORACLE_SERIAL_THREADS
 // Deterministic schedule: a std::thread stand-in whose constructor runs the
 // callable immediately on the calling thread.  Workers therefore execute in

@@ -1,0 +1,5 @@
+// Oracle shim (test infrastructure)
+#pragma once
+namespace std_msgs {
+struct ColorRGBA { float r, g, b, a; ColorRGBA() : r(0), g(0), b(0), a(0) {} };
+}

@@ -1,0 +1,6 @@
+// Oracle shim (test infrastructure)
+#pragma once
+#include "visualization_msgs/Marker.h"
+namespace visualization_msgs {
+struct MarkerArray { std::vector<Marker> markers; };
+}

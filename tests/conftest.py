@@ -71,3 +71,20 @@ def fields_close(a, b, rtol=1e-4):
             assert np.allclose(x[m], y[m], rtol=rtol, atol=1e-6), f
         else:
             assert np.array_equal(x, y), f
+
+
+@pytest.fixture(scope="session")
+def node_hostemu_lib(oracle_built):
+    """The product's node-level host logic (csrc/dsm_surfel_map.cpp) over a CPU stand-in for the engine
+    (tests/node_hostemu.cpp + the C restatement oracle): lets the pose-graph code run without a GPU."""
+    out = os.path.join(ROOT, "tests", "_build", "libnode_hostemu.so")
+    deps = [os.path.join(ROOT, "tests", "node_hostemu.cpp"),
+            os.path.join(ROOT, "densesurfelmapping_amd", "csrc", "dsm_surfel_map.cpp"),
+            os.path.join(ROOT, "include", "dsm_surfel_map.h"), os.path.join(ROOT, "include", "dsm.h"),
+            os.path.join(oracle_built, "liboracle_port.so")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-subobject-linkage",
+              "-I" + os.path.join(ROOT, "include"), deps[0], "-o", out, "-L" + oracle_built, "-l:liboracle_port.so",
+              "-Wl,-rpath," + oracle_built])
+    return out

@@ -258,12 +258,15 @@ def test_c_abi_exports_every_declared_symbol():
     """include/dsm.h <-> libdsm_hip.so <-> api.ABI_SYMBOLS agree (load only, no compute without a GPU)."""
     from densesurfelmapping_amd import api, build
     build.build_library()
-    header = open(os.path.join(ROOT, "include", "dsm.h")).read()
-    declared = set(re.findall(r"\b(dsm_[a-z_0-9]+)\s*\(", header))
-    assert declared == set(api.ABI_SYMBOLS), declared ^ set(api.ABI_SYMBOLS)
+    from densesurfelmapping_amd import surfel_map
     lib = C.CDLL(api.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), name
+    for hdr, symbols in (("dsm.h", api.ABI_SYMBOLS), ("dsm_surfel_map.h", surfel_map.ABI_SYMBOLS)):
+        header = open(os.path.join(ROOT, "include", hdr)).read()
+        header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # prose in comments mentions functions of the other header
+        declared = set(re.findall(r"\b(dsm_[a-z_0-9]+)\s*\(", header))
+        assert declared == set(symbols), (hdr, declared ^ set(symbols))
+        for name in declared:
+            assert hasattr(lib, name), name
     lib.dsm_abi_version.restype = C.c_int
     assert lib.dsm_abi_version() == 1
     assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
@@ -353,3 +356,82 @@ def test_cpp_facade_links_and_refuses_without_gpu(oracle_built):
         assert r.returncode == 0, r.stdout + r.stderr
     else:
         assert r.returncode == 77, r.stdout + r.stderr
+
+
+# ----------------------------------------------------------------------------------------------------------
+# node level (SurfelMap: message callbacks, pose graph, active / inactive sets, loop-closure warp, exports)
+
+def _node_cases():
+    import node_state
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "node_golden.json")))
+    assert [c["name"] for c in gold["cases"]] == [c["name"] for c in node_state.SCENARIOS]
+    return list(zip(node_state.SCENARIOS, gold["cases"]))
+
+
+def _check_node_run(case, gold, make_node):
+    """Run a scenario and compare with the golden record of the reference node, most telling check first."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_node_golden
+    import node_state
+    briefs, checkpoints, final, files = make_node_golden.run_case(case, make_node)
+    for i, (a, b) in enumerate(zip(briefs, gold["briefs"])):
+        assert a == b, f"{case['name']}: after pose message {i}: [fused, keyframes, local, inactive] = {a}, reference {b}"
+    assert len(briefs) == len(gold["briefs"])
+    ref_final = np.load(os.path.join(ROOT, "tests", "golden", gold["final"]))
+    for key in ("attached_counts", "begin", "is_local", "links"):
+        assert np.array_equal(final[key], ref_final[key]), (case["name"], key)
+    assert final["poses"].tobytes() == ref_final["poses"].tobytes(), "keyframe poses (fp64) differ"
+    for key in ("local", "attached"):
+        assert fields_equal(final[key], ref_final[key]) == [], (case["name"], key)
+    assert np.array_equal(final["cloud"].view("u4"), ref_final["cloud"].view("u4")), "inactive_pointcloud"
+    assert checkpoints == gold["checkpoints"]
+    assert node_state.digest(final) == gold["final_digest"]
+    for kind in ("pcd", "ply"):
+        assert files[kind]["head"] == gold["files"][kind]["head"], kind
+        assert files[kind]["bytes"] == gold["files"][kind]["bytes"], kind
+        assert files[kind]["sha256"] == gold["files"][kind]["sha256"], kind
+
+
+def test_node_golden_is_the_reference_node(oracle_built, ob, synth):
+    """tests/golden/node_* are outputs of the reference's own surfel_map.cpp (compiled in place); regenerate
+    and compare wherever the reference is present."""
+    if not ob.have_ref("map"):
+        pytest.skip("reference sources not present (GPU box): golden fixtures are used as committed")
+    for case, gold in _node_cases():
+        _check_node_run(case, gold, lambda cam, d: ob.RefSurfelMap(cam, drift_free_poses=d))
+
+
+def test_node_host_logic_matches_reference_node(node_hostemu_lib, synth):
+    """csrc/dsm_surfel_map.cpp (stamp matching, KITTI transform, pose graph, drift-free window, inactive-set
+    bookkeeping, warp matrices, PCD / PLY writers) over a CPU stand-in engine == the reference node, bit for bit."""
+    from densesurfelmapping_amd import surfel_map
+    emu = C.CDLL(node_hostemu_lib)
+    for case, gold in _node_cases():
+        _check_node_run(case, gold, lambda cam, d: surfel_map.SurfelMap(cam, drift_free_poses=d, _library=emu))
+
+
+def test_node_refuses_what_the_reference_would_crash_on(node_hostemu_lib, synth):
+    from densesurfelmapping_amd import api, surfel_map
+    emu = C.CDLL(node_hostemu_lib)
+    cam = synth.NODE_CAM
+    node = surfel_map.SurfelMap(cam, drift_free_poses=3, _library=emu)
+    img, dep, _ = synth.render(cam, synth.Scene(), 0)
+    with pytest.raises(api.DsmError):   # cv_bridge conversions are not part of the library
+        node.image_input((1, 0), img, encoding="bgr8")
+    with pytest.raises(api.DsmError):   # wrong size
+        node.image_input((1, 0), img[:-8])
+    cov = np.zeros(36)
+    cov[1] = 3.0                        # reference keyframe that does not exist: poses_database[3] on an empty database
+    with pytest.raises(api.DsmError):
+        node.orb_results_input((1, 0), [], np.zeros((1, 7)), synth.pose7(np.eye(4)), cov)
+    cov[1] = 0.0
+    node.orb_results_input((1, 0), [], np.stack([synth.pose7(np.eye(4))]), synth.pose7(np.eye(4)), cov)
+    assert node.pose_count == 1 and node.frames_fused == 0   # pose queued, no image yet
+    node.image_input((1, 0), img)
+    node.depth_input((1, 0), dep)
+    assert node.frames_fused == 1 and len(node.local_surfels()) > 0
+    with pytest.raises(api.DsmError):   # empty loop path with keyframes present: SM.cpp:258-262 reads poses[-1]
+        node.orb_results_input((1, 100000000), [], np.zeros((0, 7)), synth.pose7(np.eye(4)), cov)
+    with pytest.raises(api.DsmError):   # no point passes update_times >= 5 yet and the inactive set is empty
+        node.save_cloud(os.path.join(ROOT, "tests", "_build", "empty.PCD"))
+    node.close()
