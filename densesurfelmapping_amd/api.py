@@ -275,6 +275,40 @@ class FusionFunctions:
         a = np.ascontiguousarray(surfels, SURFEL_DTYPE)
         self._check(self._lib.dsm_map_append(self._h, _ptr(a), len(a)))
 
+    # ---- inactive store (device-side attached_surfels + inactive_pointcloud of surfel_map.cpp)
+    def store_deactivate(self, key):
+        """move_add_surfels removal into the device store; returns the segment (begin, n)."""
+        b, n = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.dsm_store_deactivate(self._h, key, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    def store_activate(self, begin, n):
+        self._check(self._lib.dsm_store_activate(self._h, begin, n))
+
+    def store_erase(self, begin, n):
+        self._check(self._lib.dsm_store_erase(self._h, begin, n))
+
+    def store_warp(self, offsets, mats, changed):
+        """offsets [g+1] tile the store; mats [g,4,4] row-major numpy; changed [g] bool."""
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        mats_cm = np.ascontiguousarray(np.asarray(mats, np.float32).transpose(0, 2, 1)).reshape(-1, 16)
+        ch = np.ascontiguousarray(changed, np.uint8)
+        self._check(self._lib.dsm_store_warp(self._h, len(offsets) - 1, _ptr(offsets), _ptr(mats_cm), _ptr(ch)))
+
+    def store_size(self) -> int:
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_store_size(self._h, C.byref(n)))
+        return n.value
+
+    def store_download(self, begin=0, n=None):
+        """(surfels, xyzi) of store[begin, begin+n)."""
+        if n is None:
+            n = self.store_size() - begin
+        s = np.zeros(max(n, 1), SURFEL_DTYPE)
+        c = np.zeros((max(n, 1), 4), np.float32)
+        self._check(self._lib.dsm_store_download(self._h, begin, n, _ptr(s), _ptr(c)))
+        return s[:n].copy(), c[:n].copy()
+
     def frame_upload(self, slot, image, depth):
         image, depth = self._frame_args(image, depth)
         self._check(self._lib.dsm_frame_upload(self._h, slot, _ptr(image), image.strides[0], _ptr(depth),

@@ -499,6 +499,75 @@ def test_state_level_stable_skip(mods):
         ff.close()
 
 
+def test_inactive_store_matches_host_model(mods):
+    """dsm_store_*: the device-side attached_surfels + inactive_pointcloud of surfel_map.cpp:1456-1595 / 681-748
+    against the oracle's extract / warp on host arrays: deactivate in order, grouped warp with untouched and
+    empty groups and the stale last point of every warped group, activate, erase with the tail moving down."""
+    api, synth, ob = mods
+    cam, scene, orc, local = _fused_map(mods, n_frames=12)
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
+    ff.map_upload(local.astype(api.SURFEL_DTYPE))
+    rng = np.random.default_rng(3)
+    store = np.zeros(0, ob.SURFEL_DTYPE)
+    cloud = np.zeros((0, 4), np.float32)
+    segs = []
+    keys = [0, 5, 1, 2]  # keyframe 5 does not exist: an empty segment in the middle
+    for key in keys:
+        b, n = ff.store_deactivate(key)
+        local, out = ob.port_extract_key(local, key)
+        assert (b, n) == (len(store), len(out)), (key, b, n, len(store), len(out))
+        segs.append((b, n))
+        store = np.concatenate([store, out])
+        cloud = np.concatenate([cloud, np.stack([out["px"], out["py"], out["pz"], out["color"]], axis=1).astype(np.float32)])
+    assert sum(n for _, n in segs) > 1000 and segs[1][1] == 0
+    assert fields_equal(ff.map_download(), local.astype(api.SURFEL_DTYPE)) == []
+
+    def check(tag):
+        s, c = ff.store_download()
+        assert ff.store_size() == len(store), tag
+        assert fields_equal(s, store.astype(api.SURFEL_DTYPE)) == [], tag
+        assert np.array_equal(c.view("u4"), cloud.view("u4")), tag
+
+    check("after deactivation")
+    # loop closure: groups 0 and 3 move, 1 is empty, 2 stays
+    offsets = np.array([b for b, _ in segs] + [len(store)], np.int32)
+    mats = np.stack([_random_rigid(rng) for _ in keys])
+    changed = np.array([1, 1, 0, 1], np.uint8)
+    ff.store_warp(offsets, mats, changed)
+    for g in range(len(keys)):
+        if not changed[g]:
+            continue
+        b, e = offsets[g], offsets[g + 1]
+        store[b:e] = ob.port_warp(store[b:e], mats[g])
+        if e - b > 1:  # SM.cpp:742: [&front, &back) -- the last point of the patch keeps its old position
+            cloud[b:e - 1] = np.stack([store["px"][b:e - 1], store["py"][b:e - 1], store["pz"][b:e - 1], store["color"][b:e - 1]], axis=1)
+    check("after warp")
+    # re-activate group 2 (keyframe 1), then erase it: the tail (group 3) moves down
+    b2, n2 = segs[2]
+    ff.store_activate(b2, n2)
+    local = np.concatenate([local, store[b2:b2 + n2]])
+    ff.store_erase(b2, n2)
+    store = np.concatenate([store[:b2], store[b2 + n2:]])
+    cloud = np.concatenate([cloud[:b2], cloud[b2 + n2:]])
+    check("after erase")
+    assert fields_equal(ff.map_download(), local.astype(api.SURFEL_DTYPE)) == []
+    with pytest.raises(api.DsmError):
+        ff.store_erase(len(store) - 1, 5)
+    with pytest.raises(api.DsmError):
+        ff.store_warp(offsets, mats, changed)  # offsets no longer tile the store
+    ff.close()
+
+
+def test_node_matches_reference_node(mods):
+    """The whole node (message callbacks -> pose graph -> active / inactive sets -> per-frame engine -> loop-closure
+    warp -> PCD / PLY export) on the GPU against the golden record of the reference's own surfel_map.cpp
+    (tests/golden/make_node_golden.py): every keyframe pose, surfel, inactive point and exported byte."""
+    import test_cpu
+    from densesurfelmapping_amd import surfel_map
+    for case, gold in test_cpu._node_cases():
+        test_cpu._check_node_run(case, gold, lambda cam, d: surfel_map.SurfelMap(cam, drift_free_poses=d))
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
     sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL)."""
