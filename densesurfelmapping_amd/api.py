@@ -41,6 +41,7 @@ DSM_MAX_STAGES = 32
 # every symbol include/dsm.h declares
 ABI_SYMBOLS = (
     "dsm_abi_version", "dsm_config_init", "dsm_create", "dsm_destroy", "dsm_last_error",
+    "dsm_host_alloc", "dsm_host_free",
     "dsm_fuse_initialize_map", "dsm_fuse_map",
     "dsm_map_upload", "dsm_map_size", "dsm_map_download", "dsm_map_copy_to_device",
     "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
@@ -96,6 +97,9 @@ def load_library():
     lib.dsm_create.argtypes = [C.POINTER(_Config), C.POINTER(_vp)]
     lib.dsm_destroy.argtypes = [_vp]
     lib.dsm_destroy.restype = None
+    lib.dsm_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    lib.dsm_host_free.argtypes = [_vp]
+    lib.dsm_host_free.restype = None
     lib.dsm_fuse_initialize_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int32,
                                             _vp, C.c_int32, _vp]
     lib.dsm_fuse_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_int32, _vp]

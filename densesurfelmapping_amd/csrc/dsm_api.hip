@@ -48,6 +48,8 @@ struct dsm_handle {
     int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
     FrameParams *d_params = nullptr;
     float *d_warp = nullptr; // 16 floats
+    uint8_t *d_stage_img = nullptr; // one tightly packed frame on its way into a pitched slot
+    float *d_stage_depth = nullptr;
     int64_t frames_submitted = 0, frames_done = 0;
     int map_upper = 0; // host-side upper bound of the resident map size
     bool map_valid = false;
@@ -271,8 +273,31 @@ int upload_frame(dsm_handle *h, int slot, const void *image, size_t img_step, co
     if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
     uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot * h->hc.slot_elems;
     float *dd = (float *)h->hc.depth_base + (int64_t)slot * h->hc.slot_elems;
-    HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, kind, h->stream));
-    HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, kind, h->stream));
+    // tightly packed rows (the usual case): one 1-D copy each, then a repack into the pitched slot on the device
+    const bool img_tight = img_step == (size_t)w, dep_tight = depth_step == (size_t)w * 4;
+    const size_t n = (size_t)w * (size_t)hh;
+    const uint8_t *s_img = nullptr;
+    const float *s_dep = nullptr;
+    if (img_tight) {
+        if (kind == hipMemcpyDeviceToDevice) s_img = (const uint8_t *)image;
+        else {
+            HIP_TRY(h, hipMemcpyAsync(h->d_stage_img, image, n, kind, h->stream));
+            s_img = h->d_stage_img;
+        }
+    } else
+        HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, kind, h->stream));
+    if (dep_tight) {
+        if (kind == hipMemcpyDeviceToDevice) s_dep = (const float *)depth;
+        else {
+            HIP_TRY(h, hipMemcpyAsync(h->d_stage_depth, depth, n * 4, kind, h->stream));
+            s_dep = h->d_stage_depth;
+        }
+    } else
+        HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, kind, h->stream));
+    if (s_img || s_dep) {
+        const hipError_t e = launch_repack(di, dd, pitch, s_img, s_dep, w, hh, h->stream);
+        if (e != hipSuccess) return fail(h, DSM_E_HIP, "frame repack: %s", hipGetErrorString(e));
+    }
     return DSM_OK;
 }
 
@@ -388,6 +413,8 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
     CREATE_TRY(dev_alloc(h, &h->d_warp, 16));
+    CREATE_TRY(dev_alloc(h, &h->d_stage_img, (size_t)w * hh));
+    CREATE_TRY(dev_alloc(h, &h->d_stage_depth, (size_t)w * hh));
     // per-pipeline superpixel state
     int np = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
     if (np != 1 && np != 2 && np != 4 && np != 8) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4 or 8"); return bail(DSM_E_INVALID); }
@@ -471,6 +498,16 @@ void dsm_destroy(dsm_handle *h) {
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+int dsm_host_alloc(void **out, size_t bytes) {
+    if (!out) return DSM_E_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(nullptr, DSM_E_HIP, "hipHostMalloc of %zu bytes failed", bytes);
+    return DSM_OK;
+}
+void dsm_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int dsm_seed_count(const dsm_handle *h) { return h ? h->hc.n_seed : DSM_E_INVALID; }

@@ -103,6 +103,8 @@ hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, c
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st,
                        const uint8_t *d_group_on = nullptr, float4 *d_cloud = nullptr);
 hipError_t launch_mark(const DeviceCtx &ctx, int key, int n_upper, hipStream_t st);
+hipError_t launch_repack(uint8_t *d_img, float *d_depth, int pitch, const uint8_t *s_img, const float *s_depth, int w, int h,
+                         hipStream_t st);
 hipError_t launch_extract_marked(const DeviceCtx &ctx, dsm_surfel *out, int cap, float4 *cloud_out, hipStream_t st);
 hipError_t launch_extract(const DeviceCtx &ctx, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st);
 hipError_t launch_append_count(const DeviceCtx &ctx, int n, hipStream_t st);

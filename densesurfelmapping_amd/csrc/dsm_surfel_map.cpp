@@ -150,7 +150,7 @@ struct PoseElement { // surfel_map.h:36-46; attached_surfels live in the handle'
 
 struct Frame {
     dsm_stamp stamp;
-    std::vector<uint8_t> bytes; // tightly packed rows
+    uint8_t *bytes; // tightly packed rows in a page-locked block of the node's pool
 };
 
 } // namespace
@@ -159,6 +159,7 @@ struct dsm_surfel_map {
     dsm_surfel_map_config cfg;
     dsm_handle *engine = nullptr;
     std::list<Frame> image_buffer, depth_buffer;                                 // surfel_map.h:96-97
+    std::vector<uint8_t *> image_pool, depth_pool;                               // free page-locked blocks
     std::list<std::tuple<dsm_stamp, dsm_pose_msg, int>> pose_reference_buffer; // :98
     std::vector<PoseElement> poses_database;                                     // :120
     std::set<int> local_surfels_indexs;                                          // :122
@@ -335,12 +336,12 @@ int synchronize_msgs(dsm_surfel_map *m) {
     // branch pops or breaks); here it ends the search: the pose waits, as it does for an empty buffer.
     while (!m->image_buffer.empty()) {
         const double t = to_sec(m->image_buffer.front().stamp);
-        if (t < pose_reference_time) m->image_buffer.pop_front();
+        if (t < pose_reference_time) { m->image_pool.push_back(m->image_buffer.front().bytes); m->image_buffer.pop_front(); }
         else { find_image = t == pose_reference_time; break; }
     }
     while (!m->depth_buffer.empty()) {
         const double t = to_sec(m->depth_buffer.front().stamp);
-        if (t < pose_reference_time) m->depth_buffer.pop_front();
+        if (t < pose_reference_time) { m->depth_pool.push_back(m->depth_buffer.front().bytes); m->depth_buffer.pop_front(); }
         else { find_depth = t == pose_reference_time; break; }
     }
     if (!find_image || !find_depth) return DSM_OK;
@@ -356,25 +357,32 @@ int synchronize_msgs(dsm_surfel_map *m) {
     float pose16[16];
     to_float16(fuse_pose, pose16);
     const int w = m->cfg.cam_width;
-    ENGINE_TRY(m, dsm_frame_upload(m->engine, 0, m->image_buffer.front().bytes.data(), (size_t)w,
-                                   (const float *)m->depth_buffer.front().bytes.data(), (size_t)w * 4));
+    ENGINE_TRY(m, dsm_frame_upload(m->engine, 0, m->image_buffer.front().bytes, (size_t)w,
+                                   (const float *)m->depth_buffer.front().bytes, (size_t)w * 4));
     ENGINE_TRY(m, dsm_fuse_frame_resident(m->engine, 0, relative_index, pose16));
     m->pose_reference_buffer.pop_front(); // :163
     m->frames_fused++;
     return DSM_OK;
 }
 
-int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, dsm_stamp stamp, int32_t width, int32_t height, size_t step,
-               const void *data, size_t elem) {
+int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, std::vector<uint8_t *> &pool, dsm_stamp stamp, int32_t width,
+               int32_t height, size_t step, const void *data, size_t elem) {
     if (!data) return fail(m, DSM_E_INVALID, "null image data");
     if (width != m->cfg.cam_width || height != m->cfg.cam_height)
         return fail(m, DSM_E_INVALID, "image is %dx%d, the node was configured for %dx%d", width, height, m->cfg.cam_width, m->cfg.cam_height);
     if (step < (size_t)width * elem) return fail(m, DSM_E_INVALID, "row step smaller than a row");
     Frame f;
     f.stamp = stamp;
-    f.bytes.resize((size_t)width * (size_t)height * elem);
-    for (int y = 0; y < height; y++) memcpy(&f.bytes[(size_t)y * width * elem], (const uint8_t *)data + (size_t)y * step, (size_t)width * elem);
-    buffer.push_back(std::move(f));
+    if (!pool.empty()) {
+        f.bytes = pool.back();
+        pool.pop_back();
+    } else {
+        void *p = nullptr;
+        if (dsm_host_alloc(&p, (size_t)width * (size_t)height * elem) != DSM_OK) return fail(m, DSM_E_HIP, "no page-locked memory for a frame");
+        f.bytes = (uint8_t *)p;
+    }
+    for (int y = 0; y < height; y++) memcpy(f.bytes + (size_t)y * width * elem, (const uint8_t *)data + (size_t)y * step, (size_t)width * elem);
+    buffer.push_back(f);
     return DSM_OK;
 }
 
@@ -448,6 +456,10 @@ int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out
 void dsm_surfel_map_destroy(dsm_surfel_map *m) {
     if (!m) return;
     dsm_destroy(m->engine);
+    for (const Frame &f : m->image_buffer) dsm_host_free(f.bytes);
+    for (const Frame &f : m->depth_buffer) dsm_host_free(f.bytes);
+    for (uint8_t *p : m->image_pool) dsm_host_free(p);
+    for (uint8_t *p : m->depth_pool) dsm_host_free(p);
     delete m;
 }
 
@@ -458,7 +470,7 @@ int dsm_surfel_map_image_input(dsm_surfel_map *m, dsm_stamp stamp, int32_t width
     if (!m) return DSM_E_INVALID;
     if (!encoding || (strcmp(encoding, "mono8") != 0 && strcmp(encoding, "8UC1") != 0))
         return fail(m, DSM_E_INVALID, "image encoding '%s': only mono8 is taken (cv_bridge is not part of this library)", encoding ? encoding : "(null)");
-    const int rc = copy_frame(m, m->image_buffer, stamp, width, height, step, data, 1);
+    const int rc = copy_frame(m, m->image_buffer, m->image_pool, stamp, width, height, step, data, 1);
     return rc ? rc : synchronize_msgs(m);
 }
 
@@ -467,7 +479,7 @@ int dsm_surfel_map_depth_input(dsm_surfel_map *m, dsm_stamp stamp, int32_t width
     if (!m) return DSM_E_INVALID;
     if (!encoding || strcmp(encoding, "32FC1") != 0)
         return fail(m, DSM_E_INVALID, "depth encoding '%s': only 32FC1 is taken", encoding ? encoding : "(null)");
-    const int rc = copy_frame(m, m->depth_buffer, stamp, width, height, step, data, 4);
+    const int rc = copy_frame(m, m->depth_buffer, m->depth_pool, stamp, width, height, step, data, 4);
     return rc ? rc : synchronize_msgs(m);
 }
 

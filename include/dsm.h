@@ -119,6 +119,11 @@ int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image,
                  const float *depth, size_t depth_step, const float *pose16, dsm_surfel *local,
                  int32_t *n_local, int32_t cap, int32_t *n_new);
 
+/* Page-locked host memory for frames handed to dsm_frame_upload / dsm_fuse_*: uploads from it run at PCIe
+ * rate without a staging copy.  Plain malloc'ed buffers work too, slower. */
+int dsm_host_alloc(void **out, size_t bytes);
+void dsm_host_free(void *p);
+
 /* ---- resident path: map and frames stay in HBM, calls are asynchronous on the handle's stream */
 
 int dsm_map_upload(dsm_handle *h, const dsm_surfel *surfels, int32_t n);

@@ -1,0 +1,189 @@
+// dsm_surfel_map.hpp -- C++ host side above include/dsm_surfel_map.h with the reference's own class and
+// method names, so that surfel_fusion/src/ros_node.cpp wires its subscribers to it unchanged:
+//
+//   reference (surfel_map.h:48-62)                                   this header
+//   ---------------------------------------------------------------  ------------------------------------
+//   SurfelMap(ros::NodeHandle &)   params of surfel_map.cpp:13-28     dsm::SurfelMap(const Params &)
+//   image_input(const sensor_msgs::ImageConstPtr &)                   image_input(const ImagePtr &)
+//   depth_input(const sensor_msgs::ImageConstPtr &)                   depth_input(const ImagePtr &)
+//   orb_results_input(const sensor_msgs::PointCloudConstPtr &,        orb_results_input(const PointCloudPtr &,
+//       const nav_msgs::PathConstPtr &, const nav_msgs::OdometryConstPtr &)   const PathPtr &, const OdometryPtr &)
+//   save_map(const std_msgs::StringConstPtr &)                        save_map(const StringPtr &)
+//   save_cloud(string) / save_mesh(string)                            save_cloud / save_mesh
+//
+// The callbacks are templates over the message pointer type: anything with the members the reference reads
+// works -- the real ROS messages (header.stamp.sec/.nsec, width, height, step, encoding, data; channels[0].values;
+// poses[i].pose; pose.pose, pose.covariance) when roscpp is present, or the plain structs of namespace
+// dsm::msg below when it is not (this image has no ROS).  Images must already be mono8 / 32FC1: the reference
+// converts with cv_bridge::toCvCopy (surfel_map.cpp:86,96), which is not part of this library.
+// Errors: the reference returns void and prints; these throw std::runtime_error (-DDSM_NO_EXCEPTIONS: status).
+#ifndef DSM_SURFEL_MAP_HPP
+#define DSM_SURFEL_MAP_HPP
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dsm_surfel_map.h"
+
+namespace dsm {
+
+namespace msg { // ROS-free mirrors of the message fields the node reads
+struct Time {
+    uint32_t sec = 0, nsec = 0;
+};
+struct Header {
+    uint32_t seq = 0;
+    Time stamp;
+    std::string frame_id;
+};
+struct Point {
+    double x = 0, y = 0, z = 0;
+};
+struct Quaternion {
+    double x = 0, y = 0, z = 0, w = 1;
+};
+struct Pose {
+    Point position;
+    Quaternion orientation;
+};
+struct PoseStamped {
+    Header header;
+    Pose pose;
+};
+struct PoseWithCovariance {
+    Pose pose;
+    double covariance[36] = {0};
+};
+struct Image { // sensor_msgs/Image
+    Header header;
+    uint32_t height = 0, width = 0;
+    std::string encoding;
+    uint8_t is_bigendian = 0;
+    uint32_t step = 0;
+    std::vector<uint8_t> data;
+};
+struct ChannelFloat32 {
+    std::string name;
+    std::vector<float> values;
+};
+struct PointCloud { // sensor_msgs/PointCloud: channels[0].values = flat pairs of keyframe indices
+    Header header;
+    std::vector<ChannelFloat32> channels;
+};
+struct Path { // nav_msgs/Path
+    Header header;
+    std::vector<PoseStamped> poses;
+};
+struct Odometry { // nav_msgs/Odometry: pose.covariance[0] > 0 = new keyframe, [1] = reference keyframe
+    Header header;
+    PoseWithCovariance pose;
+};
+struct String {
+    std::string data;
+};
+typedef std::shared_ptr<const Image> ImageConstPtr;
+typedef std::shared_ptr<const PointCloud> PointCloudConstPtr;
+typedef std::shared_ptr<const Path> PathConstPtr;
+typedef std::shared_ptr<const Odometry> OdometryConstPtr;
+typedef std::shared_ptr<const String> StringConstPtr;
+} // namespace msg
+
+class SurfelMap {
+  public:
+    struct Params { // nh.getParam(...) of surfel_map.cpp:13-28
+        int cam_width = 0, cam_height = 0;
+        float cam_fx = 0, cam_fy = 0, cam_cx = 0, cam_cy = 0;
+        float fuse_far_distence = 30.f, fuse_near_distence = 0.5f; // kitti_orb.launch:15-16
+        int drift_free_poses = 10;
+        bool rgbd = false;
+        int device = 0;
+        int surfel_capacity = 0;
+    };
+
+    explicit SurfelMap(const Params &p) {
+        dsm_surfel_map_config c;
+        c.cam_width = p.cam_width;
+        c.cam_height = p.cam_height;
+        c.cam_fx = p.cam_fx;
+        c.cam_fy = p.cam_fy;
+        c.cam_cx = p.cam_cx;
+        c.cam_cy = p.cam_cy;
+        c.fuse_far_distence = p.fuse_far_distence;
+        c.fuse_near_distence = p.fuse_near_distence;
+        c.drift_free_poses = p.drift_free_poses;
+        c.rgbd = p.rgbd ? 1 : 0;
+        c.device = p.device;
+        c.surfel_capacity = p.surfel_capacity;
+        const int rc = dsm_surfel_map_create(&c, &m_);
+        if (rc != DSM_OK) {
+            m_ = nullptr;
+#ifndef DSM_NO_EXCEPTIONS
+            throw std::runtime_error(std::string("dsm::SurfelMap: ") + dsm_last_error(nullptr));
+#endif
+        }
+    }
+    SurfelMap(const SurfelMap &) = delete;
+    SurfelMap &operator=(const SurfelMap &) = delete;
+    ~SurfelMap() { dsm_surfel_map_destroy(m_); }
+
+    template <typename ImagePtr> int image_input(const ImagePtr &image_input) {
+        return check(dsm_surfel_map_image_input(m_, stamp_of(image_input->header.stamp), (int32_t)image_input->width,
+                                                (int32_t)image_input->height, (size_t)image_input->step,
+                                                image_input->encoding.c_str(), image_input->data.data()));
+    }
+    template <typename ImagePtr> int depth_input(const ImagePtr &depth_input) {
+        return check(dsm_surfel_map_depth_input(m_, stamp_of(depth_input->header.stamp), (int32_t)depth_input->width,
+                                                (int32_t)depth_input->height, (size_t)depth_input->step,
+                                                depth_input->encoding.c_str(), depth_input->data.data()));
+    }
+    template <typename PointCloudPtr, typename PathPtr, typename OdometryPtr>
+    int orb_results_input(const PointCloudPtr &loop_stamp_input, const PathPtr &loop_path_input, const OdometryPtr &this_pose_input) {
+        std::vector<dsm_pose_msg> path(loop_path_input->poses.size());
+        for (size_t i = 0; i < path.size(); i++) path[i] = pose_of(loop_path_input->poses[i].pose);
+        const dsm_pose_msg this_pose = pose_of(this_pose_input->pose.pose);
+        double cov[36];
+        for (int i = 0; i < 36; i++) cov[i] = this_pose_input->pose.covariance[i];
+        static const float none = 0.f;
+        const float *values = &none;
+        int32_t n_values = 0;
+        if (!loop_stamp_input->channels.empty() && !loop_stamp_input->channels[0].values.empty()) {
+            values = loop_stamp_input->channels[0].values.data();
+            n_values = (int32_t)loop_stamp_input->channels[0].values.size();
+        }
+        return check(dsm_surfel_map_orb_results_input(m_, stamp_of(loop_stamp_input->header.stamp), values, n_values, path.data(),
+                                                      (int32_t)path.size(), stamp_of(this_pose_input->header.stamp), &this_pose, cov));
+    }
+    template <typename StringPtr> int save_map(const StringPtr &save_map_input) { return save_mesh(save_map_input->data); }
+    int save_cloud(const std::string &save_path_name) { return check(dsm_surfel_map_save_cloud(m_, save_path_name.c_str())); }
+    int save_mesh(const std::string &save_path_name) { return check(dsm_surfel_map_save_mesh(m_, save_path_name.c_str())); }
+
+    dsm_surfel_map *handle() const { return m_; }
+    dsm_handle *engine() const { return dsm_surfel_map_engine(m_); }
+
+  private:
+    template <typename T> static dsm_stamp stamp_of(const T &t) {
+        dsm_stamp s;
+        s.sec = (uint32_t)t.sec;
+        s.nsec = (uint32_t)t.nsec;
+        return s;
+    }
+    template <typename P> static dsm_pose_msg pose_of(const P &p) {
+        dsm_pose_msg o;
+        o.px = p.position.x; o.py = p.position.y; o.pz = p.position.z;
+        o.qx = p.orientation.x; o.qy = p.orientation.y; o.qz = p.orientation.z; o.qw = p.orientation.w;
+        return o;
+    }
+    int check(int rc) {
+#ifndef DSM_NO_EXCEPTIONS
+        if (rc != DSM_OK) throw std::runtime_error(std::string("dsm::SurfelMap: ") + dsm_surfel_map_last_error(m_));
+#endif
+        return rc;
+    }
+    dsm_surfel_map *m_ = nullptr;
+};
+
+} // namespace dsm
+#endif

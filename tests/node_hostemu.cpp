@@ -44,6 +44,11 @@ void dsm_destroy(dsm_handle *h) {
     delete h;
 }
 const char *dsm_last_error(const dsm_handle *h) { return h ? h->err.c_str() : ""; }
+int dsm_host_alloc(void **out, size_t bytes) {
+    *out = malloc(bytes ? bytes : 1);
+    return *out ? DSM_OK : DSM_E_HIP;
+}
+void dsm_host_free(void *p) { free(p); }
 int dsm_map_upload(dsm_handle *h, const dsm_surfel *s, int32_t n) {
     h->local.assign(s, s + n);
     return DSM_OK;

@@ -358,6 +358,51 @@ def test_cpp_facade_links_and_refuses_without_gpu(oracle_built):
         assert r.returncode == 77, r.stdout + r.stderr
 
 
+def _build_node_replay_test():
+    from densesurfelmapping_amd import api, build
+    build.build_library()
+    out = os.path.join(ROOT, "tests", "_build", "node_replay_test")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    pkg = os.path.dirname(api.LIB_PATH)
+    subprocess.run(["g++", "-std=c++11", "-O1", os.path.join(ROOT, "tests", "cpp", "node_replay_test.cpp"), "-o", out,
+                    "-L" + pkg, "-ldsm_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def _write_node_events(path, cam, case, synth):
+    """The scenario's message stream in the record format of tests/cpp/node_replay_test.cpp."""
+    with open(path, "wb") as f:
+        f.write(np.array([cam.width, cam.height, case["drift_free_poses"]], "<i4").tobytes())
+        f.write(np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near], "<f4").tobytes())
+        for ev in synth.node_messages(cam, synth.Scene(), case["frames"], **case["kw"]):
+            kind = {"image": 0, "depth": 1, "orb": 2}[ev[0]]
+            f.write(np.array([kind], "<i4").tobytes() + np.array(ev[1], "<u4").tobytes())
+            if kind == 0:
+                f.write(np.ascontiguousarray(ev[2], "u1").tobytes())
+            elif kind == 1:
+                f.write(np.ascontiguousarray(ev[2], "<f4").tobytes())
+            else:
+                f.write(np.array([ev[2].size], "<i4").tobytes() + np.ascontiguousarray(ev[2], "<f4").tobytes())
+                f.write(np.array([len(ev[3])], "<i4").tobytes() + np.ascontiguousarray(ev[3], "<f8").tobytes())
+                f.write(np.ascontiguousarray(ev[4], "<f8").tobytes() + np.ascontiguousarray(ev[5], "<f8").tobytes())
+        f.write(np.array([-1], "<i4").tobytes())
+
+
+def test_cpp_surfel_map_wrapper_links_and_refuses_without_gpu(synth, tmp_path):
+    """include/dsm_surfel_map.hpp compiles as C++11 against plain message structs and links against the C ABI;
+    without a GPU the constructor must report 'no device' (exit 77), never compute."""
+    import torch
+    import node_state
+    exe = _build_node_replay_test()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the replay itself is checked by the -m gpu suite")
+    case = dict(node_state.SCENARIOS[0], frames=2)
+    ev = str(tmp_path / "events.bin")
+    _write_node_events(ev, synth.NODE_CAM, case, synth)
+    r = subprocess.run([exe, ev, str(tmp_path / "a.PCD"), str(tmp_path / "a.PLY")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+
+
 # ----------------------------------------------------------------------------------------------------------
 # node level (SurfelMap: message callbacks, pose graph, active / inactive sets, loop-closure warp, exports)
 

@@ -568,6 +568,24 @@ def test_node_matches_reference_node(mods):
         test_cpu._check_node_run(case, gold, lambda cam, d: surfel_map.SurfelMap(cam, drift_free_poses=d))
 
 
+def test_cpp_surfel_map_wrapper_replay(mods, tmp_path):
+    """include/dsm_surfel_map.hpp (the reference's class / callback names over plain message structs) replaying a
+    recorded message stream: the PCD and PLY it saves are the reference node's, byte for byte."""
+    import subprocess
+    import node_state
+    import test_cpu
+    api, synth, ob = mods
+    exe = test_cpu._build_node_replay_test()
+    case, gold = test_cpu._node_cases()[0]
+    ev, pcd, ply = str(tmp_path / "events.bin"), str(tmp_path / "map.PCD"), str(tmp_path / "map_mesh.PLY")
+    test_cpu._write_node_events(ev, synth.NODE_CAM, case, synth)
+    r = subprocess.run([exe, ev, pcd, ply], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for kind, path in (("pcd", pcd), ("ply", ply)):
+        got = node_state.file_digest(path)
+        assert got["head"] == gold["files"][kind]["head"] and got["sha256"] == gold["files"][kind]["sha256"], kind
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
     sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL)."""
