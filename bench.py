@@ -364,6 +364,28 @@ def main():
                                         "note": "per frame: pageable host image+depth H2D, fuse (one graph replay), stream sync; RGB-D constant set"}
         ff.close()
 
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # the whole node through its message callbacks (stamp matching, pose graph, active /
+        # inactive sets in HBM, loop closure at the start of the second lap), host-inclusive: every frame is copied into
+        # the node's page-locked pool and uploaded
+        from densesurfelmapping_amd import surfel_map
+        n_node = 3 * period
+        events = list(synth.node_messages(cam, scene, n_node, lap=period, frames={i: f for i, f in enumerate(rendered)}))
+        node = surfel_map.SurfelMap(cam, drift_free_poses=10, device=device, surfel_capacity=1 << 21)
+        for ev in events[:60]:
+            node.feed(ev)
+        node.local_surfels()
+        t_n = time.perf_counter()
+        for ev in events[60:]:
+            node.feed(ev)
+        n_act = len(node.local_surfels())
+        dt_n = time.perf_counter() - t_n
+        out["node_callbacks"] = {"value": round((n_node - 20) / dt_n, 1), "unit": "frames/s", "frames": n_node - 20,
+                                 "keyframes": node.pose_count, "active_surfels": n_act, "inactive_surfels": len(node.inactive_cloud()),
+                                 "note": "image_input + depth_input + orb_results_input per frame (drift_free_poses 10, keyframe every 5, "
+                                         "loop closure with warp of active and inactive surfels at frame %d); host-inclusive" % period}
+        node.close()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cam, synth.Scene(seed=12345, frames_per_period=period), synth)
 

@@ -195,6 +195,7 @@ def sequence(cam: Camera, scene: Scene, n_frames: int, start: int = 0):
 # loop_path, this_pose) send to the surfel_fusion node (ros_node.cpp:24-32), as plain tuples.
 
 NODE_CAM = Camera(320, 104, 185.0, 185.0, 159.5, 51.5)   # small frames for node-level tests (8 | W, 8 | H)
+NODE_CAM_RGBD = Camera(320, 240, 262.5, 262.5, 159.5, 119.5, far=6.0, near=0.3, rgbd=True)
 
 
 def _rot_to_quat(R: np.ndarray) -> np.ndarray:
@@ -231,7 +232,7 @@ def _drift(t: int, rate: float) -> np.ndarray:
 
 
 def node_messages(cam: Camera, scene: Scene, n_frames: int, lap: int = 40, keyframe_every: int = 5, drift_rate: float = 1.0,
-                  path_lag: int = 0, pose_first=(), drop_pose=(), extra_loops=None):
+                  path_lag: int = 0, pose_first=(), drop_pose=(), extra_loops=None, frames=None):
     """Yield the node's input messages for ``n_frames`` frames of a circuit of ``lap`` frames.
 
     The camera drives the scene's trajectory and jumps back to the start after every ``lap`` frames (a closed
@@ -244,10 +245,11 @@ def node_messages(cam: Camera, scene: Scene, n_frames: int, lap: int = 40, keyfr
       ("orb", (sec, nsec), loop_values float32[2k], loop_path float64[n,7], this_pose float64[7], covariance float64[36])
     ``pose_first``: frames whose orb message precedes their images; ``drop_pose``: frames without orb message
     (never a keyframe); ``path_lag``: the loop path misses the newest ``path_lag`` keyframes (:254-270);
-    ``extra_loops``: {frame: [(kf_a, kf_b), ...]} additional loop edges announced at that frame.
+    ``extra_loops``: {frame: [(kf_a, kf_b), ...]} additional loop edges announced at that frame;
+    ``frames``: already rendered {frame index within the lap: (image, depth)}.
     """
     extra_loops = extra_loops or {}
-    frames = {}
+    frames = dict(frames or {})
     true_kf, est_kf = [], []       # per keyframe: drift-free and estimated cam->world
     loops = []
     closed = False

@@ -26,10 +26,11 @@ import node_state  # noqa: E402
 
 def run_case(case, make_node, checkpoint_every=10):
     """Feed the scenario to a node; returns (per-orb-event briefs, checkpoint digests, final snapshot, file digests)."""
-    node = make_node(synth.NODE_CAM, case["drift_free_poses"])
+    cam, scene = node_state.camera_and_scene(case, synth)
+    node = make_node(cam, case["drift_free_poses"])
     briefs, checkpoints = [], {}
     n_orb = 0
-    for ev in synth.node_messages(synth.NODE_CAM, synth.Scene(), case["frames"], **case["kw"]):
+    for ev in synth.node_messages(cam, scene, case["frames"], **case["kw"]):
         node.feed(ev)
         if ev[0] == "orb":
             briefs.append(node_state.brief(node))
@@ -49,7 +50,7 @@ def run_case(case, make_node, checkpoint_every=10):
 
 def main():
     out = {"generator": "oracle/_ref/libdsm_ref_map.so (reference surfel_map.cpp + fusion_functions.cpp, workers run in index order at join)",
-           "camera": "NODE_CAM", "cases": []}
+           "cases": []}
     for case in node_state.SCENARIOS:
         briefs, checkpoints, final, files = run_case(case, lambda cam, d: RefSurfelMap(cam, drift_free_poses=d))
         fname = "node_" + case["name"] + "_final.npz"

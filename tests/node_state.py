@@ -13,7 +13,16 @@ SCENARIOS = [
     # frames without a pose, a second loop edge that re-activates a separate run of the inactive set
     {"name": "circuit_lag_75", "frames": 75, "drift_free_poses": 4,
      "kw": {"lap": 40, "path_lag": 2, "pose_first": (3, 17, 42), "drop_pose": (13, 26), "extra_loops": {52: [(10, 3)]}}},
+    # hand-held RGB-D camera in a room-sized scene (BASELINE configs[3] shape scaled down): the RGB-D constant set of
+    # fusion_functions.h:17-21, a keyframe every 4 frames, loop closure after 32 frames
+    {"name": "rgbd_room_48", "frames": 48, "drift_free_poses": 3, "camera": "NODE_CAM_RGBD",
+     "scene": {"seed": 5, "scale": 0.12, "step": 0.05, "frames_per_period": 40},
+     "kw": {"lap": 32, "keyframe_every": 4, "drift_rate": 0.1}},
 ]
+
+
+def camera_and_scene(case, synth):
+    return getattr(synth, case.get("camera", "NODE_CAM")), synth.Scene(**case.get("scene", {}))
 
 
 def _canon(a: np.ndarray) -> bytes:

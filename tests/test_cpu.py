@@ -371,10 +371,12 @@ def _build_node_replay_test():
 
 def _write_node_events(path, cam, case, synth):
     """The scenario's message stream in the record format of tests/cpp/node_replay_test.cpp."""
+    import node_state
+    scene = node_state.camera_and_scene(case, synth)[1]
     with open(path, "wb") as f:
         f.write(np.array([cam.width, cam.height, case["drift_free_poses"]], "<i4").tobytes())
         f.write(np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near], "<f4").tobytes())
-        for ev in synth.node_messages(cam, synth.Scene(), case["frames"], **case["kw"]):
+        for ev in synth.node_messages(cam, scene, case["frames"], **case["kw"]):
             kind = {"image": 0, "depth": 1, "orb": 2}[ev[0]]
             f.write(np.array([kind], "<i4").tobytes() + np.array(ev[1], "<u4").tobytes())
             if kind == 0:
