@@ -232,7 +232,7 @@ def _drift(t: int, rate: float) -> np.ndarray:
 
 
 def node_messages(cam: Camera, scene: Scene, n_frames: int, lap: int = 40, keyframe_every: int = 5, drift_rate: float = 1.0,
-                  path_lag: int = 0, pose_first=(), drop_pose=(), extra_loops=None, frames=None):
+                  path_lag: int = 0, pose_first=(), drop_pose=(), extra_loops=None, frames=None, ref_rng=None):
     """Yield the node's input messages for ``n_frames`` frames of a circuit of ``lap`` frames.
 
     The camera drives the scene's trajectory and jumps back to the start after every ``lap`` frames (a closed
@@ -246,7 +246,8 @@ def node_messages(cam: Camera, scene: Scene, n_frames: int, lap: int = 40, keyfr
     ``pose_first``: frames whose orb message precedes their images; ``drop_pose``: frames without orb message
     (never a keyframe); ``path_lag``: the loop path misses the newest ``path_lag`` keyframes (:254-270);
     ``extra_loops``: {frame: [(kf_a, kf_b), ...]} additional loop edges announced at that frame;
-    ``frames``: already rendered {frame index within the lap: (image, depth)}.
+    ``frames``: already rendered {frame index within the lap: (image, depth)}; ``ref_rng``: a numpy Generator that
+    picks each frame's reference keyframe among the latest three instead of the latest (fuzzing the pose graph).
     """
     extra_loops = extra_loops or {}
     frames = dict(frames or {})
@@ -266,6 +267,8 @@ def node_messages(cam: Camera, scene: Scene, n_frames: int, lap: int = 40, keyfr
             loops.append((len(true_kf), 0))
         est_pose = true_pose if closed else _drift(t, drift_rate) @ true_pose
         ref_kf = max(len(true_kf) - 1, 0)
+        if ref_rng is not None and ref_kf > 0:
+            ref_kf -= int(ref_rng.integers(0, min(3, ref_kf + 1)))
         if is_kf:
             true_kf.append(true_pose)
             est_kf.append(est_pose)

@@ -197,8 +197,9 @@ class RefSurfelMap:
     in place, oracle/ref_map_driver.cpp) behind the same message-level interface as
     densesurfelmapping_amd.surfel_map.SurfelMap."""
 
-    def __init__(self, cam, drift_free_poses=10):
-        lib = C.CDLL(ref_lib_path("map_rgbd" if cam.rgbd else "map"))
+    def __init__(self, cam, drift_free_poses=10, kind=None):
+        # kind "map_threads": real std::threads, for timing only (the reference's warp_surfels races, SM.cpp:791-824)
+        lib = C.CDLL(ref_lib_path(kind or ("map_rgbd" if cam.rgbd else "map")))
         lib.refmap_create.restype = _vp
         lib.refmap_create.argtypes = [C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_int]
         lib.refmap_destroy.argtypes = [_vp]

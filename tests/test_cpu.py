@@ -457,6 +457,43 @@ def test_node_host_logic_matches_reference_node(node_hostemu_lib, synth):
         _check_node_run(case, gold, lambda cam, d: surfel_map.SurfelMap(cam, drift_free_poses=d, _library=emu))
 
 
+def test_node_host_logic_fuzz_against_reference_node(node_hostemu_lib, ob, synth):
+    """Random pose graphs: every frame's reference keyframe drawn among the latest three, random extra loop edges,
+    random drift-free ranges -- the product's host logic (CPU stand-in engine) and the reference node side by side,
+    compared after every pose message (counts) and at the end (whole state)."""
+    if not ob.have_ref("map"):
+        pytest.skip("reference sources not present (GPU box)")
+    import node_state
+    from densesurfelmapping_amd import surfel_map
+    emu = C.CDLL(node_hostemu_lib)
+    cam, scene = synth.NODE_CAM, synth.Scene()
+    frames = {i: synth.render(cam, scene, i)[:2] for i in range(30)}
+    for seed in range(4):
+        rng = np.random.default_rng(100 + seed)
+        n = 90
+        n_kf = n // 5
+        extra = {}
+        for _ in range(6):
+            t = int(rng.integers(20, n))
+            a, b = sorted(int(v) for v in rng.integers(0, max(t // 5, 1), size=2))
+            if a != b:
+                extra.setdefault(t, []).append((b, a))
+        d = int(rng.integers(2, 6))
+        kw = dict(lap=30, extra_loops=extra, frames=frames, path_lag=int(rng.integers(0, 3)))
+        a_node = surfel_map.SurfelMap(cam, drift_free_poses=d, _library=emu)
+        b_node = ob.RefSurfelMap(cam, drift_free_poses=d)
+        ev_a = synth.node_messages(cam, scene, n, ref_rng=np.random.default_rng(seed), **kw)
+        ev_b = synth.node_messages(cam, scene, n, ref_rng=np.random.default_rng(seed), **kw)
+        for i, (ea, eb) in enumerate(zip(ev_a, ev_b)):
+            a_node.feed(ea)
+            b_node.feed(eb)
+            if ea[0] == "orb":
+                assert node_state.brief(a_node) == node_state.brief(b_node), (seed, i, n_kf)
+        assert node_state.digest(node_state.snapshot(a_node)) == node_state.digest(node_state.snapshot(b_node)), seed
+        a_node.close()
+        b_node.close()
+
+
 def test_node_refuses_what_the_reference_would_crash_on(node_hostemu_lib, synth):
     from densesurfelmapping_amd import api, surfel_map
     emu = C.CDLL(node_hostemu_lib)
