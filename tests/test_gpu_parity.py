@@ -226,6 +226,29 @@ def test_edge_inputs(mods):
         _compare_frame(name + " (2nd)", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
 
 
+def test_strided_rows_like_a_cv_mat_roi(mods):
+    """image / depth rows with a step larger than the row (a cv::Mat ROI): the pitched 2-D copy path gives the
+    same frame as the tightly packed fast path (1-D copy + device repack)."""
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene()
+    ff_a = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    ff_b = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    la = lb = np.zeros(0, api.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, 6):
+        wide_i = np.zeros((cam.height, cam.width + 24), np.uint8)
+        wide_d = np.full((cam.height, cam.width + 7), 3.0, np.float32)
+        wide_i[:, :cam.width] = img
+        wide_d[:, :cam.width] = dep
+        vi, vd = wide_i[:, :cam.width], wide_d[:, :cam.width]
+        assert vi.strides[0] != cam.width and vd.strides[0] != cam.width * 4
+        la, ka = ff_a.fuse_map(ref, img, dep, pose, la)
+        lb, kb = ff_b.fuse_map(ref, vi, vd, pose, lb)
+        assert ka == kb and np.array_equal(ff_a.labels(), ff_b.labels())
+        assert fields_equal(la, lb) == []
+    ff_a.close()
+    ff_b.close()
+
+
 def test_compaction_with_many_holes(mods):
     """Maps whose surfels are mostly stale (pruned this frame): the K < k branch with tail holes."""
     api, synth, ob = mods
