@@ -89,6 +89,32 @@ def test_resident_replay_kitti(mods):
         _compare_frame(f"kitti frame {t}", ff, orc, ff.map_download(), lo.astype(api.SURFEL_DTYPE))
 
 
+def test_parity_sequence_200_frames(mods):
+    """the 200-frame parity sequence (four scene periods: the map saturates, stale surfels are pruned,
+    holes are refilled and compacted), replayed resident in one enqueue with frame pipelining; checkpoints every 50
+    frames against the oracle, byte for byte."""
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene()
+    period = scene.frames_per_period
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 18)
+    orc = ob.PortOracle(cam)
+    frames = list(synth.sequence(cam, scene, 200))
+    for t in range(period):
+        ff.frame_upload(t, frames[t][1], frames[t][2])
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for base in range(0, 200, 50):
+        chunk = frames[base:base + 50]
+        ff.replay_enqueue(*ff.pack_replay([f[0] % period for f in chunk], [f[4] for f in chunk], [f[3] for f in chunk]))
+        for t, img, dep, pose, ref in chunk:
+            lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+        got = ff.map_download()
+        assert len(got) == len(lo), (base, len(got), len(lo))
+        assert fields_equal(got, lo.astype(api.SURFEL_DTYPE)) == [], base
+    assert (lo["update_times"] >= 5).sum() > 100
+    ff.close()
+
+
 @pytest.mark.parametrize("camera,frames", [("KITTI_1241", 4), ("FULLHD", 2)])
 def test_other_baseline_sizes(mods, camera, frames):
     """The launch-file default 1241x376 (ragged: 1241 = 155*8 + 1) and BASELINE config 5's 1920x1080, against
