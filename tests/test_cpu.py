@@ -370,24 +370,30 @@ def _build_node_replay_test():
 
 
 def _write_node_events(path, cam, case, synth):
-    """The scenario's message stream in the record format of tests/cpp/node_replay_test.cpp."""
+    """The scenario's message stream as a message log (densesurfelmapping_amd/msglog.py)."""
     import node_state
+    from densesurfelmapping_amd import msglog
     scene = node_state.camera_and_scene(case, synth)[1]
-    with open(path, "wb") as f:
-        f.write(np.array([cam.width, cam.height, case["drift_free_poses"]], "<i4").tobytes())
-        f.write(np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near], "<f4").tobytes())
-        for ev in synth.node_messages(cam, scene, case["frames"], **case["kw"]):
-            kind = {"image": 0, "depth": 1, "orb": 2}[ev[0]]
-            f.write(np.array([kind], "<i4").tobytes() + np.array(ev[1], "<u4").tobytes())
-            if kind == 0:
-                f.write(np.ascontiguousarray(ev[2], "u1").tobytes())
-            elif kind == 1:
-                f.write(np.ascontiguousarray(ev[2], "<f4").tobytes())
-            else:
-                f.write(np.array([ev[2].size], "<i4").tobytes() + np.ascontiguousarray(ev[2], "<f4").tobytes())
-                f.write(np.array([len(ev[3])], "<i4").tobytes() + np.ascontiguousarray(ev[3], "<f8").tobytes())
-                f.write(np.ascontiguousarray(ev[4], "<f8").tobytes() + np.ascontiguousarray(ev[5], "<f8").tobytes())
-        f.write(np.array([-1], "<i4").tobytes())
+    msglog.write_log(path, cam, case["drift_free_poses"], synth.node_messages(cam, scene, case["frames"], **case["kw"]))
+
+
+def test_message_log_round_trip(synth, tmp_path):
+    """write_log -> read_log returns the same messages, bit for bit."""
+    import node_state
+    from densesurfelmapping_amd import msglog
+    case = dict(node_state.SCENARIOS[1], frames=12)
+    cam = synth.NODE_CAM
+    path = str(tmp_path / "log.bin")
+    _write_node_events(path, cam, case, synth)
+    cam2, dfp, events = msglog.read_log(path)
+    assert (cam2.width, cam2.height, dfp) == (cam.width, cam.height, case["drift_free_poses"])
+    want = list(synth.node_messages(cam, synth.Scene(), case["frames"], **case["kw"]))
+    got = list(events)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and tuple(a[1]) == tuple(b[1])
+        for x, y in zip(a[2:], b[2:]):
+            assert np.asarray(x).tobytes() == np.ascontiguousarray(y, dtype=np.asarray(x).dtype).tobytes()
 
 
 def test_cpp_surfel_map_wrapper_links_and_refuses_without_gpu(synth, tmp_path):

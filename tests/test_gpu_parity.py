@@ -635,6 +635,22 @@ def test_cpp_surfel_map_wrapper_replay(mods, tmp_path):
         assert got["head"] == gold["files"][kind]["head"] and got["sha256"] == gold["files"][kind]["sha256"], kind
 
 
+def test_message_log_replay_driver(mods, tmp_path):
+    """python -m densesurfelmapping_amd.msglog: a recorded message log replayed through the Python node, exports equal
+    to the reference node's."""
+    import node_state
+    import test_cpu
+    from densesurfelmapping_amd import msglog
+    api, synth, ob = mods
+    case, gold = test_cpu._node_cases()[1]
+    log, pcd, ply = str(tmp_path / "log.bin"), str(tmp_path / "m.PCD"), str(tmp_path / "m.PLY")
+    test_cpu._write_node_events(log, synth.NODE_CAM, case, synth)
+    out = msglog.replay(log, save_cloud=pcd, save_mesh=ply)
+    assert [out["frames_fused"], out["keyframes"], out["active_surfels"], out["inactive_surfels"]] == gold["briefs"][-1]
+    for kind, path in (("pcd", pcd), ("ply", ply)):
+        assert node_state.file_digest(path)["sha256"] == gold["files"][kind]["sha256"], kind
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
     sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL)."""
