@@ -107,7 +107,11 @@ __device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph
 __device__ __forceinline__ int strip_blocks_per_row(int gw) { return (((gw + 3) >> 2) + 7) >> 3; }
 __device__ __forceinline__ int seed_of_block(int b, int wv, int gw, int gh) {
 #if !DSM_XCD_STRIPS
-    const int s = b * 4 + wv;
+    // bottom rows first: in driving scenes they are the expensive seeds (near ground, every pixel has depth, long
+    // lists), the top rows are sky and leave after the gather.  Workgroups are dispatched in index order and the
+    // grid does not fit the machine at once, so what is dispatched last must be what finishes fastest.
+    const int n_blocks = (gw * gh + 3) >> 2;
+    const int s = (n_blocks - 1 - b) * 4 + wv;
     return s < gw * gh ? s : -1;
 #endif
     const int spr = strip_blocks_per_row(gw);
