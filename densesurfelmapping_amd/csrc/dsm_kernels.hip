@@ -498,17 +498,20 @@ constexpr int kCols = 6; // LDS columns per wave, reused across phases:
 constexpr int kColStride = kWin * kWin + 4;
 
 // Ordered double sum of one accumulator over the (padded) inlier list.  Blocks of 8 whose residuals are
-// all in the Huber core take the plain path; otherwise the class of each element comes from the
-// wave-uniform masks (noncore / upper / lower), and only Jacobian lanes add the tail term.
+// all in the Huber core take the plain path.  In a block with outliers every element adds
+//     (double)(X*Y) * scale,   scale = 1 for a core element, else hr/2 in a Jacobian lane and 0 in a Hessian lane,
+// where the residual column holds +-1 instead of r for an upper / lower tail element (0 for a NaN residual): the
+// tail term +-(hr/2)*(double)Y of a Jacobian lane is (double)(+-1*Y) * (hr/2) exactly, a core term times 1.0 is
+// itself, and a Hessian lane adds +-0.  Branch-free and without per-element class logic; checked against the
+// three-way form on 8 M random elements on the host.
 // Scaling by two commutes with every rounding, so the sums are carried halved: a core term is
 // (double)(X*Y) instead of (double)((2*X)*Y), a tail term +-(hr/2)*(double)Y, and the result is doubled
 // once at the end -- bit-identical (no overflow / underflow anywhere near these magnitudes), one multiply
 // less per element.
 __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *yc, int m, const unsigned long long noncore[4],
-                                                 const unsigned long long upper[4], const unsigned long long lower[4],
                                                  bool is_j, double hr) {
     double acc = 0.0;
-    const double half_hr = 0.5 * hr;
+    const double k_lane = is_j ? 0.5 * hr : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int lim = m - k * 64 < 64 ? m - k * 64 : 64;
@@ -524,13 +527,11 @@ __device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *y
 #pragma unroll
                 for (int q = 0; q < 8; q++) acc += (double)(xs[q] * ys[q]);
             } else {
-                const unsigned u8 = (unsigned)(upper[k] >> j) & 0xffu, l8 = (unsigned)(lower[k] >> j) & 0xffu;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const bool core = !((n8 >> q) & 1u), up = (u8 >> q) & 1u, lo = (l8 >> q) & 1u;
-                    const double t_core = (double)(xs[q] * ys[q]);
-                    const double t_tail = (up ? half_hr : -1 * half_hr) * (double)ys[q];
-                    acc += core ? t_core : ((is_j && (up || lo)) ? t_tail : 0.0);
+                    const double v = (double)(xs[q] * ys[q]);
+                    const double scale = ((n8 >> q) & 1u) ? k_lane : 1.0;
+                    acc += v * scale;
                 }
             }
         }
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const float *yc = ys == 0 ? P0 : ys == 1 ? P1 : ys == 2 ? P2 : ONE;
             const int mk = (m_in + 63) >> 6;
             for (int it = 0; it < 5; it++) {
-                unsigned long long noncore[4] = {0, 0, 0, 0}, upper[4] = {0, 0, 0, 0}, lower[4] = {0, 0, 0, 0};
+                unsigned long long noncore[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k >= mk) break;
@@ -698,13 +699,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     const bool valid = i < m_in;
                     const float r = q0[k] * nx + q1[k] * ny + q2[k] * nz + nb;
                     const int cls = huber_class(r, hr);
-                    if (valid) R[i] = r;
+                    // the residual column carries the tail sign for outliers (see gn_ordered_sum)
+                    if (valid) R[i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
                     noncore[k] = __ballot(valid && cls != 0);
-                    upper[k] = __ballot(valid && cls == 1);
-                    lower[k] = __ballot(valid && cls == 2);
                 }
                 wave_lds_sync();
-                const double acc = gn_ordered_sum(xc, yc, m_in, noncore, upper, lower, is_j, hr);
+                const double acc = gn_ordered_sum(xc, yc, m_in, noncore, is_j, hr);
                 wave_lds_sync();
                 // damped solve, FF.cpp:172-180: one lane per 2x2 determinant, per adjugate entry, per row
                 if (lane < 16) SA[lane] = (lane % 5 == 0) ? acc + 5 : acc; // +5 on the diagonal
