@@ -36,6 +36,7 @@ SEED_DTYPE = np.dtype(
 assert SURFEL_DTYPE.itemsize == 44 and SEED_DTYPE.itemsize == 60
 
 DSM_FLAG_NO_GRAPH = 1
+DSM_FLAG_UPLOAD_STREAM = 2
 DSM_MAX_STAGES = 32
 
 # every symbol include/dsm.h declares

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,17 @@ struct dsm_handle {
     float *d_warp = nullptr; // 16 floats
     uint8_t *d_stage_img = nullptr; // one tightly packed frame on its way into a pitched slot
     float *d_stage_depth = nullptr;
+    // DSM_FLAG_UPLOAD_STREAM: frames go up on a stream of their own, so that the upload of the next frame overlaps the
+    // kernels of the current one; ev_slot[s] = the last frame submitted by dsm_fuse_frame_resident that reads slot s
+    // has finished (recorded on the map stream).  Otherwise up_stream == stream.
+    hipStream_t up_stream = nullptr;
+    bool own_up_stream = false;
+    std::vector<hipEvent_t> ev_slot;
+    std::vector<char> slot_used;
+    // batched replays do not pay an event per frame (a marker packet between kernels costs the 8-stream replay a fifth
+    // of its throughput): uploads that follow one wait for ev_fence, recorded once behind the batch
+    hipEvent_t ev_fence = nullptr;
+    bool fence_pending = false;
     int64_t frames_submitted = 0, frames_done = 0;
     int map_upper = 0; // host-side upper bound of the resident map size
     bool map_valid = false;
@@ -236,6 +248,7 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
     h->hc = pp.ctx;
+    h->fence_pending = true; // (timed / debug replays: uploads wait for the whole stream)
     if (hi == kNumStages - 1) { // the tail advanced the pipeline's cursor
         h->frames_submitted++;
         if (with_compaction) {
@@ -262,6 +275,8 @@ int sync_and_fetch_counts(dsm_handle *h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->frames_done = h->frames_submitted;
     h->map_upper = h->h_scalars[0];
+    h->fence_pending = false; // nothing is in flight any more
+    std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
     return check_status(h);
 }
 
@@ -273,6 +288,15 @@ int upload_frame(dsm_handle *h, int slot, const void *image, size_t img_step, co
     if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
     uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot * h->hc.slot_elems;
     float *dd = (float *)h->hc.depth_base + (int64_t)slot * h->hc.slot_elems;
+    hipStream_t up = h->up_stream;
+    if (h->own_up_stream) {
+        if (h->fence_pending) { // frames enqueued by a batched / timed replay may read any slot
+            HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(up, h->ev_fence, 0));
+            h->fence_pending = false;
+        }
+        if (h->slot_used[(size_t)slot]) HIP_TRY(h, hipStreamWaitEvent(up, h->ev_slot[(size_t)slot], 0)); // frames still reading this slot
+    }
     // tightly packed rows (the usual case): one 1-D copy each, then a repack into the pitched slot on the device
     const bool img_tight = img_step == (size_t)w, dep_tight = depth_step == (size_t)w * 4;
     const size_t n = (size_t)w * (size_t)hh;
@@ -281,23 +305,24 @@ int upload_frame(dsm_handle *h, int slot, const void *image, size_t img_step, co
     if (img_tight) {
         if (kind == hipMemcpyDeviceToDevice) s_img = (const uint8_t *)image;
         else {
-            HIP_TRY(h, hipMemcpyAsync(h->d_stage_img, image, n, kind, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_stage_img, image, n, kind, up));
             s_img = h->d_stage_img;
         }
     } else
-        HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, kind, h->stream));
+        HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, kind, up));
     if (dep_tight) {
         if (kind == hipMemcpyDeviceToDevice) s_dep = (const float *)depth;
         else {
-            HIP_TRY(h, hipMemcpyAsync(h->d_stage_depth, depth, n * 4, kind, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_stage_depth, depth, n * 4, kind, up));
             s_dep = h->d_stage_depth;
         }
     } else
-        HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, kind, h->stream));
+        HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, kind, up));
     if (s_img || s_dep) {
-        const hipError_t e = launch_repack(di, dd, pitch, s_img, s_dep, w, hh, h->stream);
+        const hipError_t e = launch_repack(di, dd, pitch, s_img, s_dep, w, hh, up);
         if (e != hipSuccess) return fail(h, DSM_E_HIP, "frame repack: %s", hipGetErrorString(e));
     }
+    HIP_TRY(h, hipStreamSynchronize(up)); // the frame is in its slot, the caller may reuse its buffers
     return DSM_OK;
 }
 
@@ -380,6 +405,11 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->up_stream = h->stream;
+    if (cfg->flags & DSM_FLAG_UPLOAD_STREAM) {
+        CREATE_TRY(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+        h->own_up_stream = true;
+    }
 
     DeviceCtx &c = h->hc;
     memset(&c, 0, sizeof c);
@@ -413,6 +443,9 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
     CREATE_TRY(dev_alloc(h, &h->d_warp, 16));
+    h->ev_slot.assign((size_t)c.n_slots, nullptr);
+    h->slot_used.assign((size_t)c.n_slots, 0);
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_fence, hipEventDisableTiming));
     CREATE_TRY(dev_alloc(h, &h->d_stage_img, (size_t)w * hh));
     CREATE_TRY(dev_alloc(h, &h->d_stage_depth, (size_t)w * hh));
     // per-pipeline superpixel state
@@ -487,6 +520,10 @@ void dsm_destroy(dsm_handle *h) {
         if (pp.stream) (void)hipStreamDestroy(pp.stream);
     }
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->own_up_stream && h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
+    for (hipEvent_t e : h->ev_slot)
+        if (e) (void)hipEventDestroy(e);
+    if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
@@ -829,10 +866,7 @@ int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_s
     if (!h) return DSM_E_INVALID;
     int rc = bind_device(h);
     if (rc) return rc;
-    if ((rc = upload_frame(h, slot, image, img_step, depth, depth_step, hipMemcpyHostToDevice))) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the caller may reuse its buffers
-    h->frames_done = h->frames_submitted;
-    return DSM_OK;
+    return upload_frame(h, slot, image, img_step, depth, depth_step, hipMemcpyHostToDevice);
 }
 
 int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size_t img_step, const void *depth_dev,
@@ -840,10 +874,7 @@ int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size
     if (!h) return DSM_E_INVALID;
     int rc = bind_device(h);
     if (rc) return rc;
-    if ((rc = upload_frame(h, slot, image_dev, img_step, depth_dev, depth_step, hipMemcpyDeviceToDevice))) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->frames_done = h->frames_submitted;
-    return DSM_OK;
+    return upload_frame(h, slot, image_dev, img_step, depth_dev, depth_step, hipMemcpyDeviceToDevice);
 }
 
 int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, const float *pose16) {
@@ -853,7 +884,13 @@ int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, 
     int rc = bind_device(h);
     if (rc) return rc;
     if ((rc = stage_params(h, slot, reference_frame_index, pose16))) return rc;
-    return submit_frame(h, true);
+    if ((rc = submit_frame(h, true))) return rc;
+    if (!h->own_up_stream) return DSM_OK;
+    // live path: the next upload into this slot waits for exactly this frame
+    if (!h->ev_slot[(size_t)slot]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_slot[(size_t)slot], hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->ev_slot[(size_t)slot], h->stream));
+    h->slot_used[(size_t)slot] = 1;
+    return DSM_OK;
 }
 
 int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
@@ -869,6 +906,7 @@ int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int
             if ((rc = submit_frame(h, true))) return rc;
         i += m;
     }
+    if (n) h->fence_pending = true;
     return DSM_OK;
 }
 

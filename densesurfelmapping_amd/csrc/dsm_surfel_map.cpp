@@ -357,9 +357,11 @@ int synchronize_msgs(dsm_surfel_map *m) {
     float pose16[16];
     to_float16(fuse_pose, pose16);
     const int w = m->cfg.cam_width;
-    ENGINE_TRY(m, dsm_frame_upload(m->engine, 0, m->image_buffer.front().bytes, (size_t)w,
+    // two frame slots in turn: this frame goes up (on the engine's upload stream) while the previous one is still being fused
+    const int slot = (int)(m->frames_fused & 1);
+    ENGINE_TRY(m, dsm_frame_upload(m->engine, slot, m->image_buffer.front().bytes, (size_t)w,
                                    (const float *)m->depth_buffer.front().bytes, (size_t)w * 4));
-    ENGINE_TRY(m, dsm_fuse_frame_resident(m->engine, 0, relative_index, pose16));
+    ENGINE_TRY(m, dsm_fuse_frame_resident(m->engine, slot, relative_index, pose16));
     m->pose_reference_buffer.pop_front(); // :163
     m->frames_fused++;
     return DSM_OK;
@@ -441,7 +443,8 @@ int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out
                     cfg->fuse_near_distence, cfg->rgbd ? 1 : 0);
     ec.device = cfg->device;
     ec.surfel_capacity = cfg->surfel_capacity;
-    ec.pipeline_depth = 1; // live callbacks: one frame at a time
+    ec.pipeline_depth = 1; // live callbacks: one frame at a time,
+    ec.flags |= DSM_FLAG_UPLOAD_STREAM; // the next frame goes up while this one is fused
     int rc = dsm_create(&ec, &m->engine); // SurfelMap::SurfelMap -> fusion_functions.initialize (:53)
     if (rc == DSM_OK) rc = dsm_map_upload(m->engine, nullptr, 0);
     if (rc != DSM_OK) {

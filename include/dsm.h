@@ -90,6 +90,10 @@ typedef struct dsm_config {
 } dsm_config;
 
 #define DSM_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying a hipGraph */
+#define DSM_FLAG_UPLOAD_STREAM 2u /* dsm_frame_upload runs on a stream of its own, overlapping the frames in flight
+                                     on other slots (live feeds).  Off by default: HIP spreads streams over 4
+                                     hardware queues in creation order, and one more stream per handle spreads the
+                                     map streams of many handles unevenly (8-subsequence replay: -22 %). */
 
 typedef struct dsm_handle dsm_handle;
 
@@ -173,9 +177,14 @@ int dsm_store_size(dsm_handle *h, int32_t *n);
 /* either output may be NULL; xyzi_out receives 4 floats per point (x, y, z, intensity).  Synchronises. */
 int dsm_store_download(dsm_handle *h, int32_t begin, int32_t n, dsm_surfel *surfels_out, float *xyzi_out);
 
+/* Copy a frame into frame slot `slot` (0 .. frame_slots-1 of the config) and return when it is there (the host
+ * buffers may be reused).  By default the copy is ordered behind everything enqueued so far.  With
+ * DSM_FLAG_UPLOAD_STREAM it runs on the handle's upload stream instead: it waits only for the enqueued frames that
+ * still read this slot and overlaps frames in flight on OTHER slots -- alternate two slots to upload frame t+1
+ * while frame t is fused. */
 int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
                      size_t depth_step);
-/* same, sources already in device memory */
+/* same, sources already in device memory (the caller makes sure they have been written) */
 int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size_t img_step,
                             const void *depth_dev, size_t depth_step);
 

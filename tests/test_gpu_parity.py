@@ -275,6 +275,34 @@ def test_strided_rows_like_a_cv_mat_roi(mods):
     ff_b.close()
 
 
+def test_frame_upload_device_and_slot_reuse(mods):
+    """dsm_frame_upload_device from torch tensors == host upload; and uploads into a slot whose previous frame is
+    still in flight wait for it (two alternating slots, nothing synchronised in between)."""
+    import torch
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene()
+    frames = list(synth.sequence(cam, scene, 24))
+    ff_h = api.FusionFunctions.from_camera(cam, frame_slots=2, surfel_capacity=65536, flags=api.DSM_FLAG_UPLOAD_STREAM)
+    ff_d = api.FusionFunctions.from_camera(cam, frame_slots=2, surfel_capacity=65536)
+    ff_h.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    ff_d.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    orc = ob.PortOracle(cam)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in frames:
+        ti, td = torch.from_numpy(img.copy()).cuda(), torch.from_numpy(dep.copy()).cuda()
+        torch.cuda.synchronize()
+        ff_h.frame_upload(t & 1, img, dep)
+        ff_d.frame_upload_device(t & 1, ti.data_ptr(), cam.width, td.data_ptr(), cam.width * 4)
+        ff_h.fuse_frame_resident(t & 1, ref, pose)   # no synchronisation: the next upload overlaps this frame
+        ff_d.fuse_frame_resident(t & 1, ref, pose)
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+    want = lo.astype(api.SURFEL_DTYPE)
+    assert fields_equal(ff_h.map_download(), want) == []
+    assert fields_equal(ff_d.map_download(), want) == []
+    ff_h.close()
+    ff_d.close()
+
+
 def test_compaction_with_many_holes(mods):
     """Maps whose surfels are mostly stale (pruned this frame): the K < k branch with tail holes."""
     api, synth, ob = mods
