@@ -836,16 +836,23 @@ int dsm_store_warp(dsm_handle *h, int32_t n_groups, const int32_t *offsets, cons
     int rc = bind_device(h);
     if (rc) return rc;
     const size_t b_m = sizeof(float) * 16 * (size_t)n_groups, b_o = sizeof(int32_t) * ((size_t)n_groups + 1);
-    char *d = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d, b_m + b_o + (size_t)n_groups));
+    const size_t need = b_m + b_o + (size_t)n_groups;
+    if (need > h->store_tmp_bytes) { // the scratch of dsm_store_erase doubles as the argument block; grow-only
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
+        h->d_store_tmp = nullptr;
+        h->store_tmp_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_store_tmp, need * 2));
+        h->store_tmp_bytes = need * 2;
+    }
+    char *d = (char *)h->d_store_tmp;
     hipError_t e = hipMemcpyAsync(d, mats16, b_m, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + b_m, offsets, b_o, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + b_m + b_o, changed, (size_t)n_groups, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess)
         e = launch_warp(h->d_store, nullptr, h->store_n, (const float *)d, (const int32_t *)(d + b_m), n_groups, h->store_n, h->stream,
                         (const uint8_t *)(d + b_m + b_o), h->d_cloud);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the host arrays may be reused, the scratch freed
-    (void)hipFree(d);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the host arrays may be reused
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "store warp: %s", hipGetErrorString(e));
     return DSM_OK;
 }

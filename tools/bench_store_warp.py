@@ -56,5 +56,5 @@ print(json.dumps({"metric": "inactive surfels warped/sec (loop closure, 200 keyf
                   "us_per_call": round(dt * 1e6, 1), "us_per_deactivate_call": round(t_deact * 1e6, 1),
                   "alg_bytes_per_surfel": 104, "achieved_GBps": round(gbs, 1), "hbm_peak_GBps": 8000.0,
                   "frac": round(gbs / 8000.0, 4),
-                  "note": "whole dsm_store_warp call: scratch hipMalloc, three small uploads, one kernel, synchronise, free; "
+                  "note": "whole dsm_store_warp call: three small uploads, one kernel, synchronise; "
                           "kernel-only time is in the rocprofv3 trace"}))
