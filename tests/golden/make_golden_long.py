@@ -1,0 +1,80 @@
+"""Generate tests/golden/long_golden.json from the REFERENCE's own translation unit: the SURVEY.md §8(d)
+parity sequence at the headline resolution (200 frames at 1226x370) and a large-map compaction case.
+
+Runs only where /root/reference exists (this container): oracle/_ref/libdsm_ref_serial.so is
+surfel_fusion/src/fusion_functions.cpp compiled in place (oracle/Makefile, `make ref`).  Only digests are
+committed (the maps themselves are 8 MB and more): per frame the SHA-256 of the label image, the new / total
+surfel counts and the number of deleted slots the frame's compaction consumed; every 50 frames the
+NaN-canonical SHA-256 of the whole surfel array (tests/node_state.py `_canon`).
+
+    python tests/golden/make_golden_long.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from densesurfelmapping_amd import synth  # noqa: E402
+from node_state import _canon  # noqa: E402
+from oracle.bindings import SURFEL_DTYPE, RefOracle  # noqa: E402
+import scale_cases  # noqa: E402
+
+
+def map_sha(a):
+    return hashlib.sha256(_canon(np.ascontiguousarray(a, SURFEL_DTYPE))).hexdigest()
+
+
+def long_sequence():
+    case = {"name": "kitti1226_drive_200", "camera": "KITTI_1226", "scene": {"seed": 12345}, "frames": 200, "checkpoint_every": 50}
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    ref = RefOracle(cam)
+    local = np.zeros(0, SURFEL_DTYPE)
+    per_frame, checkpoints = [], {}
+    for t, img, dep, pose, ridx in synth.sequence(cam, scene, case["frames"]):
+        before = len(local)
+        local, k = ref.fuse_map(ridx, img, dep, pose, local)
+        per_frame.append({"n_new": int(k), "n_local": int(len(local)), "n_holes": int(before + k - len(local)),
+                          "labels_sha256": hashlib.sha256(ref.labels().tobytes()).hexdigest()})
+        if (t + 1) % case["checkpoint_every"] == 0:
+            checkpoints[str(t + 1)] = map_sha(local)
+            print(case["name"], "frame", t + 1, "surfels", len(local), flush=True)
+    return dict(case, per_frame=per_frame, map_sha256=checkpoints,
+                n_mature=int((local["update_times"] >= 5).sum()))
+
+
+def large_map(case):
+    """One fuse_map into a 600 k-surfel map with 10-90 % of it stale (pruned by this frame): the compaction's
+    multi-round hole scan, the saturated fuse grid and the K < k tail-hole chains at a realistic size.  With the
+    FULLHD_2M case: BASELINE configs[4], one 1920x1080 frame fused into a 2 M-surfel map."""
+    out = []
+    cam = getattr(synth, case["camera"])
+    base, frame = scale_cases.large_map_inputs(RefOracle(cam), synth, SURFEL_DTYPE, case)
+    t, img, dep, pose, ridx = frame
+    for trial in case["trials"]:
+        m = scale_cases.large_map_variant(base, trial)
+        ref = RefOracle(cam)
+        after, k = ref.fuse_map(ridx, img, dep, pose, m)
+        out.append({"trial": trial, "n_in": int(len(m)), "n_stale": int((m["last_update"] < 0).sum()), "n_new": int(k),
+                    "n_local": int(len(after)), "n_holes": int(len(m) + k - len(after)), "in_sha256": map_sha(m),
+                    "map_sha256": map_sha(after), "labels_sha256": hashlib.sha256(ref.labels().tobytes()).hexdigest()})
+        print(case["camera"], trial, out[-1]["n_in"], "->", out[-1]["n_local"], "holes", out[-1]["n_holes"], flush=True)
+    return out
+
+
+def main():
+    out = {"generator": "oracle/_ref/libdsm_ref_serial.so (reference fusion_functions.cpp, serial thread schedule)",
+           "sequence": long_sequence(), "large_map": large_map(scale_cases.LARGE_MAP),
+           "fullhd_2m": large_map(scale_cases.FULLHD_2M)}
+    with open(os.path.join(HERE, "long_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -525,3 +525,36 @@ def test_node_refuses_what_the_reference_would_crash_on(node_hostemu_lib, synth)
     with pytest.raises(api.DsmError):   # no point passes update_times >= 5 yet and the inactive set is empty
         node.save_cloud(os.path.join(ROOT, "tests", "_build", "empty.PCD"))
     node.close()
+
+
+# ------------------------------------------------------------------ parity at scale (vectors: tests/golden/make_golden_long.py)
+def _map_sha(a, dtype):
+    from node_state import _canon
+    return hashlib.sha256(_canon(np.ascontiguousarray(a, dtype))).hexdigest()
+
+
+def test_port_oracle_matches_long_golden(ob, synth):
+    """oracle/dsm_oracle.c over the 200-frame 1226x370 parity sequence and the large-map cases against the digests
+    recorded from the reference's own fusion_functions.cpp: the port is what the GPU tests compare with byte for
+    byte when a digest differs, so it is pinned at these sizes too."""
+    import scale_cases
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "long_golden.json")))
+    case = gold["sequence"]
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    orc = ob.PortOracle(cam)
+    local = np.zeros(0, ob.SURFEL_DTYPE)
+    for (t, img, dep, pose, ref), want in zip(synth.sequence(cam, scene, case["frames"]), case["per_frame"]):
+        local, k = orc.fuse_map(ref, img, dep, pose, local)
+        assert (k, len(local)) == (want["n_new"], want["n_local"]), t
+        assert hashlib.sha256(orc.labels().tobytes()).hexdigest() == want["labels_sha256"], t
+        if str(t + 1) in case["map_sha256"]:
+            assert _map_sha(local, ob.SURFEL_DTYPE) == case["map_sha256"][str(t + 1)], t
+    for key, sc in (("large_map", scale_cases.LARGE_MAP), ("fullhd_2m", scale_cases.FULLHD_2M)):
+        cam = getattr(synth, sc["camera"])
+        big, (t, img, dep, pose, ref) = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, sc)
+        for trial, want in zip(sc["trials"], gold[key]):
+            m = scale_cases.large_map_variant(big, trial, synth)
+            assert _map_sha(m, ob.SURFEL_DTYPE) == want["in_sha256"], (key, trial)
+            after, k = ob.PortOracle(cam).fuse_map(ref, img, dep, pose, m)
+            assert (k, len(after)) == (want["n_new"], want["n_local"]), (key, trial)
+            assert _map_sha(after, ob.SURFEL_DTYPE) == want["map_sha256"], (key, trial)

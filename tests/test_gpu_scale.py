@@ -1,0 +1,187 @@
+"""GPU parity at scale: the regimes the short sequences of test_gpu_parity.py never reach.
+
+  * the SURVEY.md §8(d) parity sequence at the headline resolution: 200 frames at 1226x370 against vectors from
+    the reference's own translation unit (tests/golden/make_golden_long.py) -- pruning (FF.cpp:206-210) and the
+    hole refill / swap-with-last compaction (SM.cpp:1077-1109) fire at that size;
+  * maps far above 65 536 surfels: the multi-round hole scan, the saturated fuse grid (grid-stride loop) and the
+    K < k tail-hole chains, against the reference-TU digests AND the port oracle byte for byte;
+  * BASELINE configs[4]: one 1920x1080 frame fused into a 2 M-surfel map, then the loop-closure deformation of the
+    active map (dsm_map_warp) and of 200 keyframes of an inactive store of the same size (dsm_store_warp).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, fields_equal
+import scale_cases
+from node_state import _canon
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods(oracle_built):
+    import torch
+    torch.cuda.init()
+    from densesurfelmapping_amd import api, synth
+    from oracle import bindings
+    return api, synth, bindings
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "long_golden.json")))
+
+
+def map_sha(a, dtype):
+    return hashlib.sha256(_canon(np.ascontiguousarray(a, dtype))).hexdigest()
+
+
+def test_long_sequence_kitti_golden(mods, gold):
+    """200 frames at 1226x370: per frame the label image (SHA-256), new and total surfel counts; every 50 frames the
+    whole map; first frame by frame (one graph replay each), then again as four 50-frame batches with the default
+    frame pipelining.  Vectors: the reference TU."""
+    api, synth, ob = mods
+    case = gold["sequence"]
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    period = scene.frames_per_period
+    frames = list(synth.sequence(cam, scene, case["frames"]))
+    per = case["per_frame"]
+    # the regimes this test exists for do occur in the reference's run
+    assert sum(f["n_holes"] for f in per) > 1000, "no pruning / deletion in the golden run"
+    assert any(f["n_holes"] > f["n_new"] for f in per), "the K < k branch (swap-with-last) never fires"
+    assert any(0 < f["n_holes"] < f["n_new"] for f in per), "the K > k branch (refill + append) never fires"
+    assert case["n_mature"] > 1000
+
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20)
+    for t in range(period):
+        ff.frame_upload(t, frames[t][1], frames[t][2])
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    for (t, img, dep, pose, ref), want in zip(frames, per):
+        ff.fuse_frame_resident(t % period, ref, pose)
+        assert ff.last_new_count() == want["n_new"], f"frame {t}: new surfels"
+        assert ff.map_size() == want["n_local"], f"frame {t}: map size"
+        assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == want["labels_sha256"], f"frame {t}: label image"
+        if str(t + 1) in case["map_sha256"]:
+            assert map_sha(ff.map_download(), api.SURFEL_DTYPE) == case["map_sha256"][str(t + 1)], f"map after frame {t}"
+    ff.close()
+
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20)  # default pipeline depth
+    for t in range(period):
+        ff.frame_upload(t, frames[t][1], frames[t][2])
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    step = case["checkpoint_every"]
+    for base in range(0, case["frames"], step):
+        chunk = frames[base:base + step]
+        ff.replay_enqueue(*ff.pack_replay([f[0] % period for f in chunk], [f[4] for f in chunk], [f[3] for f in chunk]))
+        got = ff.map_download()
+        assert len(got) == per[base + step - 1]["n_local"]
+        assert map_sha(got, api.SURFEL_DTYPE) == case["map_sha256"][str(base + step)], f"pipelined replay, frames {base}..{base + step - 1}"
+    ff.close()
+
+
+def _large_case(mods, gold_rows, case, dropin_trial=None):
+    api, synth, ob = mods
+    cam = getattr(synth, case["camera"])
+    big, (t, img, dep, pose, ref) = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, case)
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=1, surfel_capacity=len(big) + 65536)
+    ff.frame_upload(0, img, dep)
+    out = []
+    for i, (trial, want) in enumerate(zip(case["trials"], gold_rows)):
+        m = scale_cases.large_map_variant(big, trial, synth)
+        assert want["trial"] == trial and len(m) == want["n_in"]
+        assert map_sha(m, ob.SURFEL_DTYPE) == want["in_sha256"], "the input map is not the one the golden record was made from"
+        if i == dropin_trial:  # SurfelMap::fuse_map drop-in call, host buffers in and out
+            got, k = ff.fuse_map(ref, img, dep, pose, m.astype(api.SURFEL_DTYPE))
+        else:
+            ff.map_upload(m.astype(api.SURFEL_DTYPE))
+            ff.fuse_frame_resident(0, ref, pose)
+            k = ff.last_new_count()
+            got = ff.map_download()
+        assert k == want["n_new"] and len(got) == want["n_local"], (trial, k, len(got), want["n_new"], want["n_local"])
+        assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == want["labels_sha256"]
+        assert (got["update_times"] != 0).all()
+        if map_sha(got, api.SURFEL_DTYPE) != want["map_sha256"]:  # say where: rerun on the port oracle
+            o, _ = ob.PortOracle(cam).fuse_map(ref, img, dep, pose, m)
+            raise AssertionError(f"{trial}: map differs from the reference TU's; vs port oracle: {fields_equal(got, o.astype(api.SURFEL_DTYPE))}")
+        out.append(got)
+    return ff, out, (ref, pose)
+
+
+def test_large_map_compaction_golden(mods, gold):
+    """600 k surfels, 10 / 50 / 90 % stale: tail_hole_scan needs 10 rounds (9 375 bitmap words), the fuse grid is
+    saturated (2 048 blocks x 256 < 600 k), and with 90 % stale K << k leaves ~60 k tail holes to chain through."""
+    case = scale_cases.LARGE_MAP
+    rows = gold["large_map"]
+    assert rows[0]["n_in"] > 2048 * 256 and rows[0]["n_in"] // 64 > 1024
+    assert rows[2]["n_holes"] > 50 * rows[2]["n_new"] and rows[0]["n_holes"] > rows[0]["n_new"]
+    ff, _, _ = _large_case(mods, rows, case, dropin_trial=1)
+    ff.close()
+
+
+def _random_rigid(rng, scale=0.05):
+    a = rng.normal(size=3) * scale
+    th = np.linalg.norm(a)
+    k = a / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    m = np.eye(4)
+    m[:3, :3] = R
+    m[:3, 3] = rng.normal(size=3) * 0.3
+    return m.astype(np.float32)
+
+
+def test_fullhd_2m_fuse_and_warp(mods, gold):
+    """BASELINE configs[4]: a 1920x1080 frame fused into a 2 M-surfel live map (reference-TU digests), then the
+    loop-closure deformation kernels at that size against the oracle's warp: the active map by one matrix
+    (SM.cpp:750-789), and the same 2 M surfels as the inactive store of 200 keyframes with per-keyframe matrices,
+    untouched keyframes and the stale last point of every warped patch (SM.cpp:681-748)."""
+    api, synth, ob = mods
+    case = scale_cases.FULLHD_2M
+    rows = gold["fullhd_2m"]
+    assert rows[0]["n_in"] >= 2_000_000
+    ff, maps, (ref, pose) = _large_case(mods, rows, case)
+    local = maps[0]
+    rng = np.random.default_rng(777)
+    # active map: ONE matrix for all (the resident map still holds maps[0])
+    warp = _random_rigid(rng)
+    ff.map_warp(warp)
+    got = ff.map_download()
+    want = ob.port_warp(local.astype(ob.SURFEL_DTYPE), warp).astype(api.SURFEL_DTYPE)
+    assert fields_equal(got, want) == []
+    # inactive store: give the surfels 200 keyframes, deactivate them all (order of keys shuffled), warp
+    n_key = 200
+    lu = (np.arange(len(got)) * 2654435761 % (1 << 32) >> 8) % n_key
+    got["last_update"] = lu.astype(np.int32)
+    ff.map_upload(got)
+    model = got.astype(ob.SURFEL_DTYPE)
+    store = []
+    offsets = [0]
+    keys = rng.permutation(n_key)
+    for key in keys:
+        b, n = ff.store_deactivate(int(key))
+        seg = model[model["last_update"] == key]
+        assert (b, n) == (offsets[-1], len(seg))
+        store.append(seg)
+        offsets.append(b + n)
+    assert ff.map_size() == len(model)  # slots are marked deleted, the array keeps its length until the next fuse
+    store = np.concatenate(store)
+    cloud = np.stack([store["px"], store["py"], store["pz"], store["color"]], axis=1).astype(np.float32)
+    offsets = np.array(offsets, np.int32)
+    mats = np.stack([_random_rigid(rng) for _ in keys])
+    changed = (rng.random(n_key) < 0.7).astype(np.uint8)
+    ff.store_warp(offsets, mats, changed)
+    for g in range(n_key):
+        if not changed[g]:
+            continue
+        b, e = offsets[g], offsets[g + 1]
+        store[b:e] = ob.port_warp(store[b:e], mats[g])
+        if e - b > 1:
+            cloud[b:e - 1] = np.stack([store["px"][b:e - 1], store["py"][b:e - 1], store["pz"][b:e - 1], store["color"][b:e - 1]], axis=1)
+    s, c = ff.store_download()
+    assert fields_equal(s, store.astype(api.SURFEL_DTYPE)) == []
+    assert np.array_equal(c.view("u4"), cloud.view("u4"))
+    ff.close()
