@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "dsm_abi_version", "dsm_config_init", "dsm_create", "dsm_destroy", "dsm_last_error",
     "dsm_host_alloc", "dsm_host_free",
     "dsm_fuse_initialize_map", "dsm_fuse_map",
-    "dsm_map_upload", "dsm_map_size", "dsm_map_download", "dsm_map_copy_to_device",
+    "dsm_map_upload", "dsm_map_size", "dsm_map_capacity", "dsm_map_download", "dsm_map_copy_to_device",
     "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
     "dsm_store_deactivate", "dsm_store_activate", "dsm_store_erase", "dsm_store_warp", "dsm_store_size",
     "dsm_store_download",
@@ -106,6 +106,7 @@ def load_library():
     lib.dsm_fuse_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_int32, _vp]
     lib.dsm_map_upload.argtypes = [_vp, _vp, C.c_int32]
     lib.dsm_map_size.argtypes = [_vp, _vp]
+    lib.dsm_map_capacity.argtypes = [_vp, _vp]
     lib.dsm_map_download.argtypes = [_vp, _vp, C.c_int32, _vp]
     lib.dsm_map_copy_to_device.argtypes = [_vp, _vp, C.c_int32, _vp]
     lib.dsm_map_warp.argtypes = [_vp, _vp]
@@ -205,8 +206,12 @@ class FusionFunctions:
             raise TypeError("image must be uint8 (CV_8UC1) and depth float32 (CV_32FC1)")
         if image.shape != (self.height, self.width) or depth.shape != (self.height, self.width):
             raise ValueError("image/depth shape does not match initialize()")
-        if image.strides[1] != 1 or depth.strides[1] != 4:
-            image, depth = np.ascontiguousarray(image), np.ascontiguousarray(depth)
+        # the C side takes a pointer and a positive row step >= one row (a cv::Mat): anything else -- element stride
+        # other than the item size, flipped (negative step) or broadcast (step smaller than a row) views -- is copied
+        if image.strides[1] != 1 or image.strides[0] < self.width:
+            image = np.ascontiguousarray(image)
+        if depth.strides[1] != 4 or depth.strides[0] < self.width * 4:
+            depth = np.ascontiguousarray(depth)
         return image, depth
 
     # fusion_functions.h:88-94: returns (local_surfels updated, new_surfels)
@@ -243,6 +248,11 @@ class FusionFunctions:
     def map_size(self) -> int:
         n = C.c_int32(0)
         self._check(self._lib.dsm_map_size(self._h, C.byref(n)))
+        return n.value
+
+    def map_capacity(self) -> int:
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_map_capacity(self._h, C.byref(n)))
         return n.value
 
     def map_download(self) -> np.ndarray:

@@ -169,6 +169,18 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
 
 int fuse_grid_bound(const dsm_handle *h) { return h->hc.cap; }
 
+// grow-only device scratch of the handle (tail copy of dsm_store_erase, argument blocks of the warps)
+int scratch_reserve(dsm_handle *h, size_t need) {
+    if (need <= h->store_tmp_bytes) return DSM_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
+    h->d_store_tmp = nullptr;
+    h->store_tmp_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->d_store_tmp, need * 2));
+    h->store_tmp_bytes = need * 2;
+    return DSM_OK;
+}
+
 int capture(dsm_handle *h, hipStream_t st, const DeviceCtx &ctx, bool with_compaction, int lo, int hi, hipGraphExec_t *out) {
     if (*out) return DSM_OK;
     hipGraph_t g = nullptr;
@@ -369,10 +381,9 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     const int w = cfg->width, hh = cfg->height;
     if (w < 3 * kCell || hh < 3 * kCell || w > 32767 || hh > 32767)
         return fail(nullptr, DSM_E_INVALID, "image size %dx%d out of range", w, hh);
-    // A ragged border wider than 4 pixels leaves pixels with no candidate seed; the reference then
-    // indexes superpixel_seeds[-1] (FF.cpp:442-451).  Refuse instead of inventing behaviour.
-    if (w % kCell > kCell / 2 || hh % kCell > kCell / 2)
-        return fail(nullptr, DSM_E_INVALID, "image size %dx%d: (size mod 8) > 4 is undefined in the reference", w, hh);
+    // (size mod 8) > 4 (KITTI's 1242x375, 1238x374) leaves border pixels with no candidate seed: they are labelled
+    // -1 and belong to no superpixel (dsm_math.h, has_candidate_cell) -- the reference runs these sizes the same
+    // way, through reads and writes of superpixel_seeds[-1] that happen to be harmless (FF.cpp:442-451).
     if ((w / kCell) * (hh / kCell) > 64 * 1024) return fail(nullptr, DSM_E_INVALID, "more than 65536 superpixels");
     if (!(cfg->fx != 0) || !(cfg->fy != 0)) return fail(nullptr, DSM_E_INVALID, "zero focal length");
 
@@ -616,6 +627,12 @@ int dsm_map_size(dsm_handle *h, int32_t *n) {
     return DSM_OK;
 }
 
+int dsm_map_capacity(const dsm_handle *h, int32_t *cap) {
+    if (!h || !cap) return DSM_E_INVALID;
+    *cap = h->hc.cap;
+    return DSM_OK;
+}
+
 int dsm_map_download(dsm_handle *h, dsm_surfel *out, int32_t cap, int32_t *n) {
     if (!h || !n || cap < 0) return DSM_E_INVALID;
     int rc = bind_device(h);
@@ -669,18 +686,15 @@ int dsm_warp_grouped_device(dsm_handle *h, void *surfels_device, int32_t n_group
         if (offsets[g] > offsets[g + 1] || offsets[0] != 0) return fail(h, DSM_E_INVALID, "offsets must start at 0 and ascend");
     int rc = bind_device(h);
     if (rc) return rc;
-    float *d_m = nullptr;
-    int32_t *d_o = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d_m, sizeof(float) * 16 * (size_t)n_groups));
-    hipError_t e = hipMalloc((void **)&d_o, sizeof(int32_t) * ((size_t)n_groups + 1));
-    if (e != hipSuccess) { (void)hipFree(d_m); return fail(h, DSM_E_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
-    e = hipMemcpy(d_m, mats16, sizeof(float) * 16 * (size_t)n_groups, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_o, offsets, sizeof(int32_t) * ((size_t)n_groups + 1), hipMemcpyHostToDevice);
+    // argument block (matrices, offsets) in the handle's grow-only scratch, like dsm_store_warp
+    const size_t b_m = sizeof(float) * 16 * (size_t)n_groups, b_o = sizeof(int32_t) * ((size_t)n_groups + 1);
+    if ((rc = scratch_reserve(h, b_m + b_o))) return rc;
+    char *d = (char *)h->d_store_tmp;
+    hipError_t e = hipMemcpyAsync(d, mats16, b_m, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + b_m, offsets, b_o, hipMemcpyHostToDevice, h->stream);
     const int n = offsets[n_groups];
-    if (e == hipSuccess) e = launch_warp((dsm_surfel *)surfels_device, nullptr, n, d_m, d_o, n_groups, n, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_m);
-    (void)hipFree(d_o);
+    if (e == hipSuccess) e = launch_warp((dsm_surfel *)surfels_device, nullptr, n, (const float *)d, (const int32_t *)(d + b_m), n_groups, n, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the host arrays may be reused
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "grouped warp: %s", hipGetErrorString(e));
     return DSM_OK;
 }
@@ -807,14 +821,7 @@ int dsm_store_erase(dsm_handle *h, int32_t begin, int32_t n) {
     const int tail = h->store_n - (begin + n);
     if (n && tail) { // the tail moves down through a scratch copy (the ranges overlap)
         const size_t need = sizeof(dsm_surfel) * (size_t)tail;
-        if (need > h->store_tmp_bytes) {
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
-            h->d_store_tmp = nullptr;
-            h->store_tmp_bytes = 0;
-            HIP_TRY(h, hipMalloc(&h->d_store_tmp, need * 2));
-            h->store_tmp_bytes = need * 2;
-        }
+        if ((rc = scratch_reserve(h, need))) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->d_store_tmp, h->d_store + begin + n, need, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->d_store + begin, h->d_store_tmp, need, hipMemcpyDeviceToDevice, h->stream));
         const size_t need_c = sizeof(float4) * (size_t)tail;
@@ -837,14 +844,7 @@ int dsm_store_warp(dsm_handle *h, int32_t n_groups, const int32_t *offsets, cons
     if (rc) return rc;
     const size_t b_m = sizeof(float) * 16 * (size_t)n_groups, b_o = sizeof(int32_t) * ((size_t)n_groups + 1);
     const size_t need = b_m + b_o + (size_t)n_groups;
-    if (need > h->store_tmp_bytes) { // the scratch of dsm_store_erase doubles as the argument block; grow-only
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
-        h->d_store_tmp = nullptr;
-        h->store_tmp_bytes = 0;
-        HIP_TRY(h, hipMalloc(&h->d_store_tmp, need * 2));
-        h->store_tmp_bytes = need * 2;
-    }
+    if ((rc = scratch_reserve(h, need))) return rc; // the scratch of dsm_store_erase doubles as the argument block
     char *d = (char *)h->d_store_tmp;
     hipError_t e = hipMemcpyAsync(d, mats16, b_m, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + b_m, offsets, b_o, hipMemcpyHostToDevice, h->stream);

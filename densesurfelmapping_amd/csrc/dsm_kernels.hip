@@ -248,7 +248,11 @@ template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const Devi
     }
     __syncthreads();
     const int x = bx + (tid & (kTileW - 1)), y = by + tid / kTileW;
-    if (x < w && y < h) {
+    if (x < w && y < h && !has_candidate_cell(x, y, gw, gh)) {
+        // ragged border beyond every cell's reach: label -1 in both label buffers, once per frame (no later stage
+        // reads or writes these pixels: every seed window ends before them)
+        if (FIRST) c->label[y * pitch + x] = c->label_alt[y * pitch + x] = -1;
+    } else if (x < w && y < h) {
         const int p = y * pitch + x;
         const float pix_i = (float)img[p];
         const float pix_d = dep[p];
@@ -822,11 +826,13 @@ __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx) {
             if (oc == kFuseNeedPixel) {
                 const int p = vi * c->pitch + ui;
                 const int sidx = c->label[p];
-                const dsm_seed *sp = &c->seeds[sidx];
-                SeedView sd;
-                sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
-                sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
-                sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+                SeedView sd = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // label -1 (ragged border): the all-zero seed, see has_candidate_cell
+                if (sidx >= 0) {
+                    const dsm_seed *sp = &c->seeds[sidx];
+                    sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
+                    sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
+                    sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+                }
                 oc = fuse_update(fc, ref_idx, fp.pose, e, pc, nc, dep[p], sd);
                 if (oc == kFuseFused) { c->seeds[sidx].fused = 1; c->fused_flag[sidx] = 1; }
             }

@@ -68,9 +68,17 @@ DSM_HD float pixel_inv_depth(float d) {
     return invd;
 }
 
+// Pixels right of / below the last cell centre by 4 or more have no candidate cell at all (only when
+// (size mod 8) > 4, e.g. KITTI's 1242x375): the reference labels them -1 and then reads and writes
+// superpixel_seeds[-1] (FF.cpp:400,442-451,242), memory in front of the vector.  Policy here (and in the
+// oracle restatement): label -1, member of no superpixel, never stable; fusion treats seed -1 as an all-zero
+// record (the free-space test still applies, then the surfel is skipped).
+DSM_HD bool has_candidate_cell(int x, int y, int gw, int gh) { return x < gw * kCell + kCell / 2 && y < gh * kCell + kCell / 2; }
+
 // Pick the seed of pixel (x,y): candidates are the <=2x2 in-grid cells whose centre is closer
 // than one cell in both axes, visited x-offset outer / y-offset inner, strict '<' (FF.cpp:413-451).
 // load(gx, gy, sx, sy, si, has_depth, inv_depth) fetches the cost-side state of grid cell (gx,gy).
+// Returns -1 when every candidate cost is >= the 1e6 sentinel (or there is no candidate).
 template <typename LoadSeed>
 DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeed load) {
     const float invd = pixel_inv_depth(pix_d);

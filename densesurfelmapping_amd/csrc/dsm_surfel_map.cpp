@@ -140,12 +140,21 @@ double to_sec(dsm_stamp s) { return (double)s.sec + 1e-9 * (double)s.nsec; }
 
 // ------------------------------------------------------------------ node state
 struct PoseElement { // surfel_map.h:36-46; attached_surfels live in the handle's store
-    int n_attached = 0;
     dsm_pose_msg cam_pose, loop_pose;
     std::vector<int> linked_pose_index;
-    int points_begin_index = -1;
-    int points_pose_index = -1;
+    int segment = -1; // index into dsm_surfel_map::segments while the keyframe is inactive, else -1
     dsm_stamp cam_stamp = {0, 0};
+};
+
+// The inactive set as a segment table.  The handle's store holds the surfels of the inactive keyframes back to
+// back in deactivation order; entry i of the table says which keyframe owns the i-th run and how long it is, and a
+// run starts where the runs before it end.  This one table is what the reference spreads over three members:
+// PoseElement::attached_surfels.size() (count), PoseElement::points_begin_index (start) and
+// pointcloud_pose_index / PoseElement::points_pose_index (the table order and its inverse), surfel_map.h:36-46,134.
+struct Segment {
+    int keyframe;
+    int begin; // sum of the counts before this entry (kept, not recomputed: the taps read it)
+    int count;
 };
 
 struct Frame {
@@ -163,7 +172,9 @@ struct dsm_surfel_map {
     std::list<std::tuple<dsm_stamp, dsm_pose_msg, int>> pose_reference_buffer; // :98
     std::vector<PoseElement> poses_database;                                     // :120
     std::set<int> local_surfels_indexs;                                          // :122
-    std::vector<int> pointcloud_pose_index;                                      // :134
+    std::vector<Segment> segments;                                               // inactive set, store order (:134)
+    int64_t poses_dropped = 0;
+    bool failed = false; // an engine call failed half-way through a state change: refuse further input
     Mat4 transform_kitti = identity4();                                          // function-static at surfel_map.cpp:215
     int64_t frames_fused = 0;
     std::string err;
@@ -220,70 +231,79 @@ void get_add_remove_poses(const dsm_surfel_map *m, int root_index, std::vector<i
         if (std::find(driftfree_poses.begin(), driftfree_poses.end(), p) == driftfree_poses.end()) pose_to_remove.push_back(p);
 }
 
-// SurfelMap::move_add_surfels (:1456-1595)
+// SurfelMap::move_add_surfels (:1456-1595): keyframes that left the drift-free window hand their surfels to the
+// inactive set, keyframes that entered it get theirs back.
 int move_add_surfels(dsm_surfel_map *m, int reference_index) {
     std::vector<int> poses_to_add, poses_to_remove;
     get_add_remove_poses(m, reference_index, poses_to_add, poses_to_remove);
 
-    for (int inactive_index : poses_to_remove) { // :1467-1503
-        PoseElement &pe = m->poses_database[inactive_index];
-        int32_t begin = 0, n = 0;
-        ENGINE_TRY(m, dsm_store_deactivate(m->engine, inactive_index, &begin, &n));
-        pe.points_begin_index = begin; // == inactive_pointcloud->size() before the move
-        pe.points_pose_index = (int)m->pointcloud_pose_index.size();
-        m->pointcloud_pose_index.push_back(inactive_index);
-        pe.n_attached += n;
-        m->local_surfels_indexs.erase(inactive_index);
+    // Check before anything is changed: the returning surfels must fit (deactivation only frees slots, so the
+    // bound holds whatever it removes).  After this point an engine failure leaves map, store and table out of
+    // step, and the node refuses further input (`failed`).
+    if (!poses_to_add.empty()) {
+        int64_t returning = 0;
+        for (int k : poses_to_add) {
+            const int sg = m->poses_database[(size_t)k].segment;
+            if (sg < 0) return fail(m, DSM_E_STATE, "keyframe %d is neither local nor in the inactive set", k);
+            returning += m->segments[(size_t)sg].count;
+        }
+        int32_t live = 0, cap = 0;
+        ENGINE_TRY(m, dsm_map_size(m->engine, &live));
+        ENGINE_TRY(m, dsm_map_capacity(m->engine, &cap));
+        if ((int64_t)live + returning > (int64_t)cap)
+            return fail(m, DSM_E_CAPACITY, "%lld returning surfels do not fit: %d of %d slots in use", (long long)returning, live, cap);
+    }
+#define CHANGE_TRY(expr)                                          \
+    do {                                                          \
+        const int rc_ = (expr);                                   \
+        if (rc_ != DSM_OK) {                                      \
+            m->failed = true;                                     \
+            return engine_fail(m, rc_, #expr);                    \
+        }                                                         \
+    } while (0)
+
+    // leaving keyframes, ascending (:1467-1503): each becomes the last segment
+    for (int k : poses_to_remove) {
+        Segment sg;
+        sg.keyframe = k;
+        CHANGE_TRY(dsm_store_deactivate(m->engine, k, &sg.begin, &sg.count)); // begin == store size before the move
+        m->poses_database[(size_t)k].segment = (int)m->segments.size();
+        m->segments.push_back(sg);
+        m->local_surfels_indexs.erase(k);
     }
 
-    if (!poses_to_add.empty()) { // :1504-1594
+    if (!poses_to_add.empty()) {
         m->local_surfels_indexs.insert(poses_to_add.begin(), poses_to_add.end());
-        // :1583-1590 first: the surfels still sit at their store offsets (the reference holds them in a
-        // second container, so its order of the two steps does not matter)
-        for (int pose_index : poses_to_add) {
-            const PoseElement &pe = m->poses_database[pose_index];
-            if (pe.n_attached) ENGINE_TRY(m, dsm_store_activate(m->engine, pe.points_begin_index, pe.n_attached));
+        // their surfels go to the end of the active map in the order of poses_to_add (:1583-1590) ...
+        for (int k : poses_to_add) {
+            const Segment &sg = m->segments[(size_t)m->poses_database[(size_t)k].segment];
+            if (sg.count) CHANGE_TRY(dsm_store_activate(m->engine, sg.begin, sg.count));
         }
-        // :1511-1579: erase their runs from the inactive set, keeping the begin / pose indices of the rest
-        std::vector<std::pair<int, int>> remove_info;
-        for (int add_index : poses_to_add) remove_info.push_back(std::make_pair(m->poses_database[add_index].points_pose_index, add_index));
-        std::sort(remove_info.begin(), remove_info.end(),
-                  [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
-        for (const auto &ri : remove_info)
-            if (ri.first < 0) return fail(m, DSM_E_STATE, "keyframe %d is neither local nor in the inactive set", ri.second);
-        int remove_begin_index = remove_info[0].second;
-        int remove_points_size = m->poses_database[remove_begin_index].n_attached;
-        int remove_pose_size = 1;
-        for (size_t remove_i = 1; remove_i <= remove_info.size(); remove_i++) {
-            bool need_remove = remove_i == remove_info.size();
-            if (!need_remove && remove_info[remove_i].first != remove_info[remove_i - 1].first + 1) need_remove = true;
-            if (!need_remove) {
-                remove_points_size += m->poses_database[remove_info[remove_i].second].n_attached;
-                remove_pose_size += 1;
-                continue;
-            }
-            const int remove_end_index = remove_info[remove_i - 1].second;
-            ENGINE_TRY(m, dsm_store_erase(m->engine, m->poses_database[remove_begin_index].points_begin_index, remove_points_size));
-            for (size_t pi = (size_t)m->poses_database[remove_end_index].points_pose_index + 1; pi < m->pointcloud_pose_index.size(); pi++) {
-                PoseElement &later = m->poses_database[m->pointcloud_pose_index[pi]];
-                later.points_begin_index -= remove_points_size;
-                later.points_pose_index -= remove_pose_size;
-            }
-            m->pointcloud_pose_index.erase(m->pointcloud_pose_index.begin() + m->poses_database[remove_begin_index].points_pose_index,
-                                           m->pointcloud_pose_index.begin() + m->poses_database[remove_end_index].points_pose_index + 1);
-            if (remove_i < remove_info.size()) {
-                remove_begin_index = remove_info[remove_i].second;
-                remove_points_size = m->poses_database[remove_begin_index].n_attached;
-                remove_pose_size = 1;
-            }
+        // ... and their segments leave the table (:1511-1579).  Adjacent leaving segments are one erase; runs are
+        // taken from the back of the store so that the offsets of the runs still to go stay valid.
+        std::vector<char> leaving(m->segments.size(), 0);
+        for (int k : poses_to_add) leaving[(size_t)m->poses_database[(size_t)k].segment] = 1;
+        for (size_t hi = m->segments.size(); hi > 0;) {
+            if (!leaving[hi - 1]) { hi--; continue; }
+            size_t lo = hi - 1;
+            while (lo > 0 && leaving[lo - 1]) lo--;
+            const int begin = m->segments[lo].begin, end = m->segments[hi - 1].begin + m->segments[hi - 1].count;
+            if (end > begin) CHANGE_TRY(dsm_store_erase(m->engine, begin, end - begin));
+            hi = lo;
         }
-        for (int pose_index : poses_to_add) { // :1591-1593
-            PoseElement &pe = m->poses_database[pose_index];
-            pe.n_attached = 0;
-            pe.points_begin_index = -1;
-            pe.points_pose_index = -1;
+        std::vector<Segment> kept;
+        int at = 0;
+        for (size_t i = 0; i < m->segments.size(); i++) {
+            Segment sg = m->segments[i];
+            if (leaving[i]) { m->poses_database[(size_t)sg.keyframe].segment = -1; continue; }
+            sg.begin = at;
+            at += sg.count;
+            m->poses_database[(size_t)sg.keyframe].segment = (int)kept.size();
+            kept.push_back(sg);
         }
+        m->segments.swap(kept);
     }
+#undef CHANGE_TRY
     return DSM_OK;
 }
 
@@ -300,7 +320,7 @@ int warp_surfels(dsm_surfel_map *m) {
                warp_pose);
 
     // inactive keyframes: one grouped pass over the store, groups in pointcloud_pose_index order
-    const int n_groups = (int)m->pointcloud_pose_index.size();
+    const int n_groups = (int)m->segments.size();
     std::vector<int32_t> offsets((size_t)n_groups + 1, 0);
     std::vector<float> mats((size_t)n_groups * 16, 0.f);
     std::vector<uint8_t> changed((size_t)n_groups, 0);
@@ -308,8 +328,8 @@ int warp_surfels(dsm_surfel_map *m) {
     for (size_t i = 0; i < m->poses_database.size(); i++) {
         PoseElement &pe = m->poses_database[i];
         if (same_position(pe.cam_pose, pe.loop_pose)) continue; // :691-695
-        if (pe.n_attached > 0) {
-            const int g = pe.points_pose_index;
+        if (pe.segment >= 0 && m->segments[(size_t)pe.segment].count > 0) {
+            const int g = pe.segment;
             to_float16(mul(pose_to_matrix(pe.loop_pose), inverse(pose_to_matrix(pe.cam_pose))), &mats[(size_t)g * 16]); // :706-710
             changed[(size_t)g] = 1;
             any = true;
@@ -319,7 +339,7 @@ int warp_surfels(dsm_surfel_map *m) {
     if (any) {
         int32_t total = 0;
         ENGINE_TRY(m, dsm_store_size(m->engine, &total));
-        for (int g = 0; g < n_groups; g++) offsets[(size_t)g] = m->poses_database[m->pointcloud_pose_index[(size_t)g]].points_begin_index;
+        for (int g = 0; g < n_groups; g++) offsets[(size_t)g] = m->segments[(size_t)g].begin;
         offsets[(size_t)n_groups] = total;
         ENGINE_TRY(m, dsm_store_warp(m->engine, n_groups, offsets.data(), mats.data(), changed.data()));
     }
@@ -329,22 +349,31 @@ int warp_surfels(dsm_surfel_map *m) {
 
 // SurfelMap::synchronize_msgs (:103-203)
 int synchronize_msgs(dsm_surfel_map *m) {
-    if (m->pose_reference_buffer.empty()) return DSM_OK;
-    const double pose_reference_time = to_sec(std::get<0>(m->pose_reference_buffer.front()));
     bool find_image = false, find_depth = false;
-    // :114-139.  A front element NEWER than the pose stamp makes the reference's loop spin forever (neither
-    // branch pops or breaks); here it ends the search: the pose waits, as it does for an empty buffer.
-    while (!m->image_buffer.empty()) {
-        const double t = to_sec(m->image_buffer.front().stamp);
-        if (t < pose_reference_time) { m->image_pool.push_back(m->image_buffer.front().bytes); m->image_buffer.pop_front(); }
-        else { find_image = t == pose_reference_time; break; }
+    // :114-139.  Buffered frames older than the front pose are dropped, an equal stamp is the match.  A front frame
+    // NEWER than the pose stamp means the pose's own frame was lost (stamps only grow): the reference's loop then
+    // spins forever (neither branch pops or breaks).  Here that pose is dropped and counted
+    // (dsm_surfel_map_dropped_poses) and the next one is tried, so one lost message cannot stall the node.
+    for (;;) {
+        if (m->pose_reference_buffer.empty()) return DSM_OK;
+        const double pose_reference_time = to_sec(std::get<0>(m->pose_reference_buffer.front()));
+        bool lost = false;
+        find_image = find_depth = false;
+        while (!m->image_buffer.empty()) {
+            const double t = to_sec(m->image_buffer.front().stamp);
+            if (t < pose_reference_time) { m->image_pool.push_back(m->image_buffer.front().bytes); m->image_buffer.pop_front(); }
+            else { find_image = t == pose_reference_time; lost |= !find_image; break; }
+        }
+        while (!m->depth_buffer.empty()) {
+            const double t = to_sec(m->depth_buffer.front().stamp);
+            if (t < pose_reference_time) { m->depth_pool.push_back(m->depth_buffer.front().bytes); m->depth_buffer.pop_front(); }
+            else { find_depth = t == pose_reference_time; lost |= !find_depth; break; }
+        }
+        if (!lost) break;
+        m->pose_reference_buffer.pop_front();
+        m->poses_dropped++;
     }
-    while (!m->depth_buffer.empty()) {
-        const double t = to_sec(m->depth_buffer.front().stamp);
-        if (t < pose_reference_time) { m->depth_pool.push_back(m->depth_buffer.front().bytes); m->depth_buffer.pop_front(); }
-        else { find_depth = t == pose_reference_time; break; }
-    }
-    if (!find_image || !find_depth) return DSM_OK;
+    if (!find_image || !find_depth) return DSM_OK; // an empty buffer: the pose waits for its frame
 
     const dsm_pose_msg relative_pose_ros = std::get<1>(m->pose_reference_buffer.front());
     const int relative_index = std::get<2>(m->pose_reference_buffer.front());
@@ -385,6 +414,12 @@ int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, std::vector<uint8_t 
     }
     for (int y = 0; y < height; y++) memcpy(f.bytes + (size_t)y * width * elem, (const uint8_t *)data + (size_t)y * step, (size_t)width * elem);
     buffer.push_back(f);
+    // frames nobody claims (no pose ever arrives for them) must not pile up in page-locked memory: the oldest go
+    const size_t keep = m->cfg.max_buffered_frames > 0 ? (size_t)m->cfg.max_buffered_frames : 256;
+    while (buffer.size() > keep) {
+        pool.push_back(buffer.front().bytes);
+        buffer.pop_front();
+    }
     return DSM_OK;
 }
 
@@ -471,6 +506,7 @@ const char *dsm_surfel_map_last_error(const dsm_surfel_map *m) { return m ? m->e
 int dsm_surfel_map_image_input(dsm_surfel_map *m, dsm_stamp stamp, int32_t width, int32_t height, size_t step, const char *encoding,
                                const uint8_t *data) {
     if (!m) return DSM_E_INVALID;
+    if (m->failed) return fail(m, DSM_E_STATE, "the node failed half-way through a state change earlier and takes no more input");
     if (!encoding || (strcmp(encoding, "mono8") != 0 && strcmp(encoding, "8UC1") != 0))
         return fail(m, DSM_E_INVALID, "image encoding '%s': only mono8 is taken (cv_bridge is not part of this library)", encoding ? encoding : "(null)");
     const int rc = copy_frame(m, m->image_buffer, m->image_pool, stamp, width, height, step, data, 1);
@@ -480,6 +516,7 @@ int dsm_surfel_map_image_input(dsm_surfel_map *m, dsm_stamp stamp, int32_t width
 int dsm_surfel_map_depth_input(dsm_surfel_map *m, dsm_stamp stamp, int32_t width, int32_t height, size_t step, const char *encoding,
                                const void *data) {
     if (!m) return DSM_E_INVALID;
+    if (m->failed) return fail(m, DSM_E_STATE, "the node failed half-way through a state change earlier and takes no more input");
     if (!encoding || strcmp(encoding, "32FC1") != 0)
         return fail(m, DSM_E_INVALID, "depth encoding '%s': only 32FC1 is taken", encoding ? encoding : "(null)");
     const int rc = copy_frame(m, m->depth_buffer, m->depth_pool, stamp, width, height, step, data, 4);
@@ -490,6 +527,7 @@ int dsm_surfel_map_orb_results_input(dsm_surfel_map *m, dsm_stamp loop_stamp, co
                                      const dsm_pose_msg *loop_path, int32_t n_loop_path, dsm_stamp this_stamp,
                                      const dsm_pose_msg *this_pose, const double *covariance36) {
     if (!m) return DSM_E_INVALID;
+    if (m->failed) return fail(m, DSM_E_STATE, "the node failed half-way through a state change earlier and takes no more input");
     if (!this_pose || !covariance36 || n_loop_values < 0 || n_loop_path < 0 || (n_loop_values && !loop_values) || (n_loop_path && !loop_path))
         return fail(m, DSM_E_INVALID, "null/negative argument");
     std::vector<PoseElement> &db = m->poses_database;
@@ -622,8 +660,11 @@ int dsm_surfel_map_save_mesh(dsm_surfel_map *m, const char *path) {
     ENGINE_TRY(m, dsm_store_size(m->engine, &n_in));
     std::vector<dsm_surfel> inactive((size_t)n_in);
     if (n_in) ENGINE_TRY(m, dsm_store_download(m->engine, 0, n_in, inactive.data(), nullptr));
-    for (const PoseElement &pe : m->poses_database) // keyframe order, not store order
-        for (int j = 0; j < pe.n_attached; j++) push_a_surfel(vertexs, inactive[(size_t)pe.points_begin_index + (size_t)j]);
+    for (const PoseElement &pe : m->poses_database) { // keyframe order, not store order
+        if (pe.segment < 0) continue;
+        const Segment &sg = m->segments[(size_t)pe.segment];
+        for (int j = 0; j < sg.count; j++) push_a_surfel(vertexs, inactive[(size_t)sg.begin + (size_t)j]);
+    }
     std::vector<dsm_surfel> active;
     const int rc = download_active(m, active);
     if (rc) return rc;
@@ -653,6 +694,7 @@ int dsm_surfel_map_save_map(dsm_surfel_map *m, const char *path) { return dsm_su
 
 dsm_handle *dsm_surfel_map_engine(dsm_surfel_map *m) { return m ? m->engine : nullptr; }
 int64_t dsm_surfel_map_frames_fused(const dsm_surfel_map *m) { return m ? m->frames_fused : -1; }
+int64_t dsm_surfel_map_dropped_poses(const dsm_surfel_map *m) { return m ? m->poses_dropped : -1; }
 int32_t dsm_surfel_map_pose_count(const dsm_surfel_map *m) { return m ? (int32_t)m->poses_database.size() : DSM_E_INVALID; }
 
 int dsm_surfel_map_get_pose(const dsm_surfel_map *m, int32_t i, dsm_pose_msg *cam_pose, dsm_pose_msg *loop_pose, int32_t *n_attached,
@@ -661,8 +703,8 @@ int dsm_surfel_map_get_pose(const dsm_surfel_map *m, int32_t i, dsm_pose_msg *ca
     const PoseElement &pe = m->poses_database[(size_t)i];
     if (cam_pose) *cam_pose = pe.cam_pose;
     if (loop_pose) *loop_pose = pe.loop_pose;
-    if (n_attached) *n_attached = pe.n_attached;
-    if (points_begin_index) *points_begin_index = pe.points_begin_index;
+    if (n_attached) *n_attached = pe.segment >= 0 ? m->segments[(size_t)pe.segment].count : 0;
+    if (points_begin_index) *points_begin_index = pe.segment >= 0 ? m->segments[(size_t)pe.segment].begin : -1;
     if (is_local) *is_local = m->local_surfels_indexs.count(i) ? 1 : 0;
     return DSM_OK;
 }
@@ -677,9 +719,11 @@ int32_t dsm_surfel_map_get_links(const dsm_surfel_map *m, int32_t i, int32_t *ou
 int dsm_surfel_map_get_attached(dsm_surfel_map *m, int32_t i, dsm_surfel *out, int32_t cap, int32_t *n) {
     if (!m || !n || i < 0 || (size_t)i >= m->poses_database.size() || cap < 0 || (cap && !out)) return DSM_E_INVALID;
     const PoseElement &pe = m->poses_database[(size_t)i];
-    *n = pe.n_attached;
-    if (pe.n_attached > cap) return fail(m, DSM_E_CAPACITY, "%d attached surfels exceed cap %d", pe.n_attached, cap);
-    if (pe.n_attached) ENGINE_TRY(m, dsm_store_download(m->engine, pe.points_begin_index, pe.n_attached, out, nullptr));
+    const Segment none = {i, 0, 0};
+    const Segment &sg = pe.segment >= 0 ? m->segments[(size_t)pe.segment] : none;
+    *n = sg.count;
+    if (sg.count > cap) return fail(m, DSM_E_CAPACITY, "%d attached surfels exceed cap %d", sg.count, cap);
+    if (sg.count) ENGINE_TRY(m, dsm_store_download(m->engine, sg.begin, sg.count, out, nullptr));
     return DSM_OK;
 }
 

@@ -9,8 +9,6 @@ runs on "gloo" with CPU tensors in the tests).  There is no collective on the pe
 """
 from __future__ import annotations
 
-import numpy as np
-
 SURFEL_BYTES = 44
 
 
@@ -54,25 +52,3 @@ def merge_clouds(local_cloud, group=None):
     parts = [gathered[r * n_max * SURFEL_BYTES: r * n_max * SURFEL_BYTES + counts_l[r] * SURFEL_BYTES]
              for r in range(world)]
     return torch.cat(parts), counts_l
-
-
-class SubsequenceReplayer:
-    """One handle replaying one subsequence whose frames are resident in HBM.
-
-    frames: list of (image uint8 [H,W], depth float32 [H,W]) for one scene period; poses/ref_idx
-    per replayed frame; frame t uses slot t % len(frames)."""
-
-    def __init__(self, ff, frames):
-        self.ff = ff
-        self.n_slots = len(frames)
-        for i, (img, dep) in enumerate(frames):
-            ff.frame_upload(i, img, dep)
-        ff.map_upload(_empty_map())
-
-    def enqueue(self, slots, ref_idx, poses_cm):
-        self.ff.replay_enqueue(slots, ref_idx, poses_cm)
-
-
-def _empty_map():
-    from .api import SURFEL_DTYPE
-    return np.zeros(0, SURFEL_DTYPE)

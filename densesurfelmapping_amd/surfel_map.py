@@ -18,7 +18,7 @@ ABI_SYMBOLS = (
     "dsm_surfel_map_create", "dsm_surfel_map_destroy", "dsm_surfel_map_last_error",
     "dsm_surfel_map_image_input", "dsm_surfel_map_depth_input", "dsm_surfel_map_orb_results_input",
     "dsm_surfel_map_save_cloud", "dsm_surfel_map_save_mesh", "dsm_surfel_map_save_map",
-    "dsm_surfel_map_engine", "dsm_surfel_map_frames_fused", "dsm_surfel_map_pose_count",
+    "dsm_surfel_map_engine", "dsm_surfel_map_frames_fused", "dsm_surfel_map_dropped_poses", "dsm_surfel_map_pose_count",
     "dsm_surfel_map_get_pose", "dsm_surfel_map_get_links", "dsm_surfel_map_get_attached",
     "dsm_surfel_map_get_inactive_cloud",
 )
@@ -35,7 +35,7 @@ class _MapConfig(C.Structure):
                 ("cam_fx", C.c_float), ("cam_fy", C.c_float), ("cam_cx", C.c_float), ("cam_cy", C.c_float),
                 ("fuse_far_distence", C.c_float), ("fuse_near_distence", C.c_float),
                 ("drift_free_poses", C.c_int32), ("rgbd", C.c_int32), ("device", C.c_int32),
-                ("surfel_capacity", C.c_int32)]
+                ("surfel_capacity", C.c_int32), ("max_buffered_frames", C.c_int32)]
 
 
 def _bind(lib):
@@ -54,6 +54,8 @@ def _bind(lib):
         lib.dsm_surfel_map_engine.restype = _vp
         lib.dsm_surfel_map_frames_fused.argtypes = [_vp]
         lib.dsm_surfel_map_frames_fused.restype = C.c_int64
+        lib.dsm_surfel_map_dropped_poses.argtypes = [_vp]
+        lib.dsm_surfel_map_dropped_poses.restype = C.c_int64
         lib.dsm_surfel_map_pose_count.argtypes = [_vp]
         lib.dsm_surfel_map_get_pose.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]
         lib.dsm_surfel_map_get_links.argtypes = [_vp, C.c_int32, _vp, C.c_int32]
@@ -75,12 +77,13 @@ class SurfelMap:
     """``SurfelMap(nh)`` of the reference with the node's ROS parameters as keyword arguments
     (surfel_map.cpp:13-28; launch defaults of kitti_orb.launch: drift_free_poses = 10)."""
 
-    def __init__(self, cam, drift_free_poses: int = 10, device: int = 0, surfel_capacity: int = 0, _library=None):
+    def __init__(self, cam, drift_free_poses: int = 10, device: int = 0, surfel_capacity: int = 0,
+                 max_buffered_frames: int = 0, _library=None):
         # _library: tests bind the same class to their CPU stand-in build of the host logic (tests/node_hostemu.cpp)
         self._lib = _bind(_library if _library is not None else api.load_library())
         self.cam = cam
         cfg = _MapConfig(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near, drift_free_poses,
-                         1 if cam.rgbd else 0, device, surfel_capacity)
+                         1 if cam.rgbd else 0, device, surfel_capacity, max_buffered_frames)
         h = _vp()
         rc = self._lib.dsm_surfel_map_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -143,6 +146,10 @@ class SurfelMap:
     @property
     def frames_fused(self) -> int:
         return int(self._lib.dsm_surfel_map_frames_fused(self._h))
+
+    @property
+    def dropped_poses(self) -> int:
+        return int(self._lib.dsm_surfel_map_dropped_poses(self._h))
 
     @property
     def pose_count(self) -> int:

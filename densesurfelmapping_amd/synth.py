@@ -42,6 +42,9 @@ VGA_RGBD = Camera(640, 480, 525.0, 525.0, 319.5, 239.5, far=6.0, near=0.3, rgbd=
 VGA_DRIVE = Camera(640, 480, 525.0, 525.0, 319.5, 239.5)
 FULLHD = Camera(1920, 1080, 1400.0, 1400.0, 959.5, 539.5)
 TINY = Camera(160, 96, 120.0, 120.0, 79.5, 47.5)                          # unit-test size
+# (size mod 8) > 4: the rightmost / bottom pixels have no candidate superpixel (label -1, dsm_math.h has_candidate_cell)
+KITTI_1242 = Camera(1242, 375, 721.5377, 721.5377, 609.5593, 172.854)    # KITTI raw, rectified (calib_cam_to_cam P_rect_00)
+TINY_RAGGED = Camera(166, 103, 120.0, 120.0, 82.5, 51.0)
 
 
 def _hash32(x: np.ndarray) -> np.ndarray:

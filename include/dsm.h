@@ -132,6 +132,7 @@ void dsm_host_free(void *p);
 
 int dsm_map_upload(dsm_handle *h, const dsm_surfel *surfels, int32_t n);
 int dsm_map_size(dsm_handle *h, int32_t *n);                       /* synchronises */
+int dsm_map_capacity(const dsm_handle *h, int32_t *cap);           /* slots of the resident map (surfel_capacity rounded up) */
 int dsm_map_download(dsm_handle *h, dsm_surfel *out, int32_t cap, int32_t *n); /* synchronises */
 /* device-to-device copy of the resident map into caller-owned device memory (e.g. a torch
  * tensor's data_ptr) for the multi-GPU merge; synchronises. */

@@ -52,6 +52,8 @@ typedef struct dsm_surfel_map_config {
     int32_t rgbd;            /* constant set of fusion_functions.h:17-21 instead of :7-16 */
     int32_t device;          /* HIP device ordinal */
     int32_t surfel_capacity; /* active-map capacity, 0 = default of dsm_create */
+    int32_t max_buffered_frames; /* images / depths kept waiting for a pose, oldest dropped beyond; 0 = 256 (the
+                                    reference's buffers are unbounded lists, surfel_map.h:96-97) */
 } dsm_surfel_map_config;
 
 int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out); /* SurfelMap::SurfelMap */
@@ -83,6 +85,9 @@ int dsm_surfel_map_save_map(dsm_surfel_map *m, const char *path);   /* :75-81 = 
 /* ---- taps (what the publish_* methods read) ---- */
 dsm_handle *dsm_surfel_map_engine(dsm_surfel_map *m); /* active map: dsm_map_size / dsm_map_download */
 int64_t dsm_surfel_map_frames_fused(const dsm_surfel_map *m);
+/* poses whose image or depth never arrived (a newer frame was already waiting): the reference spins forever on
+ * these (surfel_map.cpp:114-139); here they are dropped so that later poses proceed */
+int64_t dsm_surfel_map_dropped_poses(const dsm_surfel_map *m);
 int32_t dsm_surfel_map_pose_count(const dsm_surfel_map *m);
 /* poses_database[i]: cam_pose, loop_pose, number of attached (inactive) surfels, points_begin_index,
  * whether i is in local_surfels_indexs; any output may be NULL */

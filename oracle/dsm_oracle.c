@@ -50,7 +50,12 @@ dsmo_ctx *dsmo_create(int w, int h, float fx, float fy, float cx, float cy, floa
     c->n_seed = c->gw * c->gh;
     c->fx = fx; c->fy = fy; c->cx = cx; c->cy = cy; c->far_d = far_d; c->near_d = near_d;
     c->huber = 0.4; c->baseline = 0.5; c->disp_err = 4.0; c->min_tol = 0.1; /* fusion_functions.h:13-16 */
-    c->seed = (dsmo_seed *)calloc((size_t)c->n_seed, sizeof(dsmo_seed));
+    /* One record in front of the table: image sizes with (size mod 8) > 4 leave border pixels without a candidate
+     * cell, and pixels whose every cost exceeds the 1e6 sentinel have none either; the reference then labels them -1
+     * and touches superpixel_seeds[-1] (FF.cpp:400,442-451, 242) -- memory in front of the vector.  The restatement
+     * pins that record: all zero at the start of a frame, i.e. never stable, no normal (fusion skips it after the
+     * free-space test).  PARITY UNPINNED for those pixels: the reference's behaviour there is undefined. */
+    c->seed = (dsmo_seed *)calloc((size_t)c->n_seed + 1, sizeof(dsmo_seed)) + 1;
     c->label = (int32_t *)calloc((size_t)w * h, sizeof(int32_t));
     c->space = (float *)calloc((size_t)w * h * 3, sizeof(float));
     c->nmap = (float *)calloc((size_t)w * h * 3, sizeof(float));
@@ -60,7 +65,7 @@ dsmo_ctx *dsmo_create(int w, int h, float fx, float fy, float cx, float cy, floa
 
 void dsmo_destroy(dsmo_ctx *c) {
     if (!c) return;
-    free(c->seed); free(c->label); free(c->space); free(c->nmap); free(c->scratch); free(c);
+    free(c->seed - 1); free(c->label); free(c->space); free(c->nmap); free(c->scratch); free(c);
 }
 
 void dsmo_set_constants(dsmo_ctx *c, double huber, double baseline, double disparity_error, double min_tolerate) {
@@ -383,7 +388,7 @@ void dsmo_calculate_norms(dsmo_ctx *c) { /* FF.cpp:916-958 */
 }
 
 void dsmo_generate_super_pixels(dsmo_ctx *c) { /* FF.cpp:960-975 */
-    memset(c->seed, 0, sizeof(dsmo_seed) * (size_t)c->n_seed);
+    memset(c->seed - 1, 0, sizeof(dsmo_seed) * ((size_t)c->n_seed + 1));
     memset(c->label, 0, sizeof(int32_t) * (size_t)c->w * c->h);
     memset(c->nmap, 0, sizeof(float) * 3 * (size_t)c->w * c->h);
     dsmo_initialize_seeds(c);

@@ -70,6 +70,10 @@ void assign(Emu &e, bool first) {
         // visit pixels in a scrambled order: the result must not depend on it
         const int p = e.order_salt ? (int)(((int64_t)q * 7919 + e.order_salt) % n) : q;
         const int x = p % e.w, y = p / e.w;
+        if (!has_candidate_cell(x, y, e.gw, e.gh)) { // ragged border: label -1 for the whole frame (k_assign)
+            if (first) e.label[p] = -1;
+            continue;
+        }
         const int pick = pick_seed(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
                                    [&](int gx, int gy, float &sx, float &sy, float &si, bool &hd, double &inv) {
                                        const int s = gy * e.gw + gx;
@@ -101,7 +105,7 @@ void resolve(Emu &e) {
 
 void apply(Emu &e) {
     for (int p = 0; p < e.w * e.h; p++)
-        if (e.tmin[e.label[p]] < p) e.label[p] = e.cand[p];
+        if (e.label[p] >= 0 && e.tmin[e.label[p]] < p) e.label[p] = e.cand[p];
 }
 
 void update_seeds(Emu &e, int sweep) {
@@ -247,7 +251,8 @@ void fuse(Emu &e, int ref_idx, const float *pose, const float *inv, dsm_surfel *
         FuseOutcome oc = fuse_project(fc, ref_idx, inv, s, ui, vi, pc, nc);
         if (oc == kFuseNeedPixel) {
             const int sidx = e.label[e.key(ui, vi)];
-            oc = fuse_update(fc, ref_idx, pose, s, pc, nc, e.D(ui, vi), view_of(e.seeds[sidx]));
+            const SeedView none = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // label -1: the all-zero seed (k_fuse_surfels)
+            oc = fuse_update(fc, ref_idx, pose, s, pc, nc, e.D(ui, vi), sidx >= 0 ? view_of(e.seeds[sidx]) : none);
             if (oc == kFuseFused) e.seeds[sidx].fused = 1;
         }
         if (oc == kFuseDeleted) local[i].update_times = 0;

@@ -57,6 +57,10 @@ int dsm_map_size(dsm_handle *h, int32_t *n) {
     *n = (int32_t)h->local.size();
     return DSM_OK;
 }
+int dsm_map_capacity(const dsm_handle *, int32_t *cap) {
+    *cap = 1 << 30;
+    return DSM_OK;
+}
 int dsm_map_download(dsm_handle *h, dsm_surfel *out, int32_t cap, int32_t *n) {
     *n = (int32_t)h->local.size();
     if (*n > cap) return DSM_E_CAPACITY;

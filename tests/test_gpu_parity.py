@@ -115,10 +115,12 @@ def test_parity_sequence_200_frames(mods):
     ff.close()
 
 
-@pytest.mark.parametrize("camera,frames", [("KITTI_1241", 4), ("FULLHD", 2)])
+@pytest.mark.parametrize("camera,frames", [("KITTI_1241", 4), ("FULLHD", 2), ("KITTI_1242", 4), ("TINY_RAGGED", 40)])
 def test_other_baseline_sizes(mods, camera, frames):
     """The launch-file default 1241x376 (ragged: 1241 = 155*8 + 1) and BASELINE config 5's 1920x1080, against
-    the oracle frame by frame."""
+    the oracle frame by frame; and sizes with (size mod 8) > 4 -- KITTI raw 1242x375 -- whose last columns / rows
+    have no candidate superpixel: label -1 there, as the reference TU also produces in this build (its accesses to
+    superpixel_seeds[-1] are undefined behaviour, so parity for those pixels is against the oracle's stated policy)."""
     api, synth, ob = mods
     cam, scene = getattr(synth, camera), synth.Scene(seed=77)
     ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 20)
@@ -130,14 +132,21 @@ def test_other_baseline_sizes(mods, camera, frames):
         lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
         assert kg == ko
         _compare_frame(f"{camera} frame {t}", ff, orc, lg, lo.astype(api.SURFEL_DTYPE))
+    if cam.width % 8 > 4 or cam.height % 8 > 4:
+        lab = ff.labels()
+        gw, gh = cam.width // 8, cam.height // 8
+        border = np.zeros_like(lab, bool)
+        border[:, gw * 8 + 4:] = True
+        border[gh * 8 + 4:, :] = True
+        assert border.any() and (lab[border] == -1).all() and (lab[~border] >= 0).all()
 
 
 def test_api_errors_are_reported(mods):
     """The reference returns void and prints; the ABI returns a status and a message, and never computes on bad input."""
     api, synth, ob = mods
     cam = synth.TINY
-    with pytest.raises(api.DsmError) as ei:  # (size mod 8) > 4: the reference would index seeds[-1]
-        api.FusionFunctions().initialize(165, 96, 100, 100, 80, 48, 30, 0.5)
+    with pytest.raises(api.DsmError) as ei:  # fewer than 3x3 superpixel cells
+        api.FusionFunctions().initialize(20, 96, 100, 100, 80, 48, 30, 0.5)
     assert ei.value.code == -1
     ff = api.FusionFunctions.from_camera(cam, surfel_capacity=128, frame_slots=2)
     img, dep, pose = synth.render(cam, synth.Scene(), 0)
