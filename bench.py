@@ -42,8 +42,10 @@ def stage_alg_bytes(stage, cam, n_seed, m_avg, k_avg):
         return n * 4 * 3
     if base == "update_seeds":
         return n * (4 + 1 + 4) + n_seed * 32
-    if base == "seed_planes":
-        return n * (4 + 4) + n_seed * (16 + 60)
+    if base == "seed_points":  # labels + depth in, per-seed state in (the centred points handed to the fit are an intermediate)
+        return n * (4 + 4) + n_seed * 16
+    if base == "seed_fit":  # seed table + prepared surfel out
+        return n_seed * (60 + 44 + 2)
     if base == "fuse_surfels":
         return m_avg * 88
     if base == "new_surfels":

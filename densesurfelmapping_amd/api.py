@@ -374,8 +374,8 @@ class FusionFunctions:
 
     # ---- state-level test taps ---------------------------------------------------------------
     STAGES = ("init_seeds", "assign_0", "update_seeds_0", "commit_seeds_0", "assign_1", "resolve_1", "update_seeds_1",
-              "commit_seeds_1", "assign_2", "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_planes", "fuse_surfels",
-              "frame_tail")
+              "commit_seeds_1", "assign_2", "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_points", "seed_fit",
+              "fuse_surfels", "frame_tail")
 
     def debug_run_stages(self, slot, reference_frame_index, pose, first, last):
         pose_cm = pose_to_colmajor(pose)
@@ -403,7 +403,7 @@ class FusionFunctions:
         self._check(self._lib.dsm_debug_set_seed_state(self._h, _ptr(core), _ptr(stable)))
 
     def debug_wave_stamps(self) -> np.ndarray:
-        out = np.zeros((4, self.n_seed, 8), np.int64)
+        out = np.zeros((5, self.n_seed, 8), np.int64)
         self._check(self._lib.dsm_debug_wave_stamps(self._h, _ptr(out)))
         return out
 

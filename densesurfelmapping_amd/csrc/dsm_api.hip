@@ -487,6 +487,8 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.stable_stage, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.tmin, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.first_empty, (size_t)kSweeps * kWorkers));
+        CREATE_TRY(dev_alloc(h, &q.gn_hdr, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.gn_pts, (size_t)c.n_seed * 3 * kGnCap));
         CREATE_TRY(dev_alloc(h, &q.seeds, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_rec, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_ok, (size_t)c.n_seed));
@@ -497,7 +499,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16;
         CREATE_TRY(dev_alloc(h, &q.cur, 1));
         if (const char *e = getenv("DSM_WAVE_STAMPS"))
-            if (e[0] == '1') CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)4 * c.n_seed * 8));
+            if (e[0] == '1') CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));
         q.params = h->d_params;
         if (np > 1) CREATE_TRY(hipEventRecord(pp.ev_map, h->stream)); // "buffers free"
     }
@@ -1021,13 +1023,13 @@ int dsm_debug_set_seed_state(dsm_handle *h, const float *core4, const int32_t *s
 }
 
 // debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_WAVE_STAMPS=1)
-int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 4 * n_seed * 8 */) {
+int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
     if (!h || !out) return DSM_E_INVALID;
     if (!h->hc.stamps) return fail(h, DSM_E_STATE, "handle was created without DSM_WAVE_STAMPS=1");
     int rc = bind_device(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out, h->hc.stamps, (size_t)4 * h->hc.n_seed * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->hc.stamps, (size_t)5 * h->hc.n_seed * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return DSM_OK;
 }
 

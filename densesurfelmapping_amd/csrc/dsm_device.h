@@ -28,6 +28,17 @@ struct FrameCur {
     const float *dep;
 };
 
+// Hand-off from k_seed_points to k_seed_fit: the start of get_huber_norm (FF.cpp:104-126) for one seed.  The centred
+// inlier points follow in gn_pts as three columns of kGnCap floats.  A superpixel's pixels lie within 8 of its centre
+// in both axes (FF.cpp:413-422): at most 15 x 15 = 225 members.
+struct GnHeader {
+    int32_t m_in;      // inliers handed to the fit; 0 = no fit, the seed keeps its defaults (FF.cpp:841, 862)
+    float nx, ny, nz;  // normalised sum of the inliers' pixel normals (FF.cpp:852-871)
+    float mx, my, mz;  // centroid (FF.cpp:111-120)
+    float far2;        // squared superpixel radius (FF.cpp:820-824)
+};
+constexpr int kGnCap = 232;
+
 // Everything a kernel needs.  Passed to every kernel BY VALUE (kernel-argument segment): the pointers and
 // sizes never change after dsm_create, so a captured graph stays valid, and a kernel reaches its data
 // without first loading a context from memory (one dependent round trip less per kernel).
@@ -58,6 +69,8 @@ struct DeviceCtx {
     int32_t *first_empty; // [kSweeps][kWorkers] first unstable seed without pixels, per worker chunk
     int32_t *worklist;    // pixel keys whose old and new seeds were both stable at sweep start
     int32_t *work_count;
+    GnHeader *gn_hdr; // [S]
+    float *gn_pts;    // [S][3][kGnCap]
     dsm_seed *seeds; // [S] final seed table, reference layout
     // what initialize_surfels (FF.cpp:315-361) would create from each seed, prepared by k_seed_planes (every
     // input but the `fused` flag is known there): the surfel, whether the seed qualifies, the flag itself
@@ -84,7 +97,7 @@ struct DeviceCtx {
     int32_t *status; // sticky device-side error bits
     FrameCur *cur; // device memory, see FrameCur
     // optional per-wave phase stamps (shader clock) of the per-seed kernels; null unless DSM_WAVE_STAMPS=1
-    long long *stamps; // [4 kernels][n_seed][8]
+    long long *stamps; // [5 kernels][n_seed][8]
 };
 
 constexpr int kStatusCapacity = 1;
@@ -93,8 +106,8 @@ constexpr int kStatusBadPick = 2;
 // launch all kernels of one frame on `stream`.  with_compaction: SurfelMap::fuse_map semantics,
 // otherwise FusionFunctions::fuse_initialize_map.  If ev != nullptr, an event is recorded before
 // the first kernel and after every kernel (ev[0..n_stages]).
-constexpr int kNumStages = 15;
-constexpr int kLastSuperpixelStage = 12; // init_seeds .. seed_planes need the frame only; fuse_surfels + frame_tail need the map
+constexpr int kNumStages = 16;
+constexpr int kLastSuperpixelStage = 13; // init_seeds .. seed_fit need the frame only; fuse_surfels + frame_tail need the map
 extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);

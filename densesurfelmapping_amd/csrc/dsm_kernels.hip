@@ -7,8 +7,10 @@
 //   k_resolve       the sequential `stable` skip rule of FF.cpp:400,445,450 as a fixed point
 //   k_update_seeds  update_seeds_kernel              FF.cpp:468-562 (+ the new label image of the sweep)
 //   k_commit_seeds  the early `return` of FF.cpp:516-517 (per worker chunk)
-//   k_seed_planes   calculate_spaces/pixels_norms/sp_depth_norms + get_huber_norm
-//                                                    FF.cpp:644-712, 792-914, 104-188
+//   k_seed_points   calculate_spaces/pixels_norms/sp_depth_norms up to the centred inlier points
+//                                                    FF.cpp:644-712, 792-871, 104-126
+//   k_seed_fit      get_huber_norm's Gauss-Newton steps, the seed's plane / position / view angle
+//                                                    FF.cpp:128-188, 872-914
 //                   and the per-seed part of initialize_surfels, FF.cpp:315-361
 //   k_fuse_surfels  fuse_surfels_kernel              FF.cpp:190-313
 //   k_frame_tail    initialize_surfels (the `fused` test and the ordered list), FF.cpp:315-361;
@@ -85,6 +87,12 @@ __device__ __forceinline__ void pad_column(float *l, int n, int lane) {
     if (lane < kBlk && n + lane < ((n + kBlk - 1) & ~(kBlk - 1))) l[n + lane] = 0.0f;
 }
 
+// issue priority of this wave by the length of its list (s_setprio takes an immediate; n is wave-uniform)
+__device__ __forceinline__ void wave_priority(int n) {
+    if (n > 96) __builtin_amdgcn_s_setprio(3);
+    else if (n > 64) __builtin_amdgcn_s_setprio(2);
+}
+
 // debug: record the shader clock of phase `ph` of seed s in per-seed kernel `kid` (lane 0 only)
 __device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph, int lane) {
     if (c->stamps && lane == 0) c->stamps[((int64_t)kid * c->n_seed + s) * 8 + ph] = clock64();
@@ -125,19 +133,26 @@ __device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const 
 __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur->dep; }
 
 // ------------------------------------------------------------------------------ init seeds
-constexpr int kScanRows = 8;
-__global__ __launch_bounds__(64) void k_init_seeds(const DeviceCtx ctx) {
+// FF.cpp:577-629.  A seed whose centre pixel has no depth takes the first depth > 0.01 of its clipped 16x16 window
+// in row-major order (FF.cpp:600-626) -- whole image regions (sky) need that at once.  Sixteen lanes per seed, lane r
+// holding window row r as four 16-byte loads issued together with the centre pixel (speculatively: whether the scan
+// is needed is only known once the centre has arrived, and a second dependent round trip costs more than the 1 KB
+// per seed read from L2); the first hit is the lowest lane with one: one ballot per wave.
+constexpr int kInitLanes = 16, kInitSeedsPerBlock = 256 / kInitLanes;
+__global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx) {
     const DeviceCtx *__restrict__ c = &ctx;
-    const int s = blockIdx.x * 64 + threadIdx.x; // one wave per workgroup: the window scans below are L1-bound, spread them
-    if (s < kSweeps * kWorkers) c->first_empty[s] = kIntMax;
-    if (s == 0) c->work_count[0] = 0;
+    const int tid = threadIdx.x, lane = lane_id();
+    const int r = tid & (kInitLanes - 1);
+    const int s = blockIdx.x * kInitSeedsPerBlock + tid / kInitLanes;
+    if (blockIdx.x == 0 && tid < kSweeps * kWorkers) c->first_empty[tid] = kIntMax;
+    if (blockIdx.x == 0 && tid == 0) c->work_count[0] = 0;
     // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
     const FrameParams &fp = c->params[(unsigned)(c->cursor[0] * c->cursor_mul + c->cursor_add) % (unsigned)c->n_params];
     const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
     const float *dep = c->depth_base + (int64_t)fp.slot * c->slot_elems;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (blockIdx.x == 0 && tid < 64) {
         FrameCur *wc = c->cur;
-        const int t = threadIdx.x;
+        const int t = tid;
         if (t < 16) wc->p.pose[t] = fp.pose[t];
         else if (t < 32) wc->p.inv[t - 16] = fp.inv[t - 16];
         else if (t == 32) { wc->p.ref_idx = fp.ref_idx; wc->p.slot = fp.slot; }
@@ -146,50 +161,43 @@ __global__ __launch_bounds__(64) void k_init_seeds(const DeviceCtx ctx) {
     }
     const int w = c->w, h = c->h, pitch = c->pitch;
     const bool live = s < c->n_seed;
-    int gx = 0, gy = 0, ix = 0, iy = 0;
-    float md = 1.0f, mi = 0.0f;
-    if (live) {
-        gx = s % c->gw; gy = s / c->gw;
-        ix = gx * kCell + kCell / 2; iy = gy * kCell + kCell / 2;
-        if (ix > w - 1) ix = w - 1;
-        if (iy > h - 1) iy = h - 1;
-        md = dep[iy * pitch + ix];
-        mi = (float)img[iy * pitch + ix];
+    const int sc = live ? s : 0;
+    const int gx = sc % c->gw, gy = sc / c->gw;
+    int ix = gx * kCell + kCell / 2, iy = gy * kCell + kCell / 2;
+    if (ix > w - 1) ix = w - 1;
+    if (iy > h - 1) iy = h - 1;
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+    const int x_lo = wx0 < 0 ? 0 : wx0, x_hi = wx0 + 2 * kCell > w - 1 ? w - 1 : wx0 + 2 * kCell;
+    const int y_lo = wy0 < 0 ? 0 : wy0, y_hi = wy0 + 2 * kCell > h - 1 ? h - 1 : wy0 + 2 * kCell;
+    const int y = wy0 + r;
+    const bool row_in = y >= y_lo && y < y_hi;
+    float md = dep[iy * pitch + ix];
+    const float mi = (float)img[iy * pitch + ix];
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = wx0 + 4 * q; // multiple of 4: 16-byte aligned, and never straddles x = 0
+        v[q] = (row_in && x >= 0) ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
     }
-    // FF.cpp:600-626: a seed whose centre has no depth takes the first depth > 0.01 of its clipped
-    // window in row-major order.  Whole image regions (sky) need it at once, so every lane scans its
-    // own window, eight rows (32 independent 16-byte loads) per round trip.
-    if (live && (double)md < 0.01) {
-        const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
-        const int x_lo = wx0 < 0 ? 0 : wx0, x_hi = wx0 + 2 * kCell > w - 1 ? w - 1 : wx0 + 2 * kCell;
-        const int y_lo = wy0 < 0 ? 0 : wy0, y_hi = wy0 + 2 * kCell > h - 1 ? h - 1 : wy0 + 2 * kCell;
-        bool found = false;
-        for (int yb = y_lo; yb < y_hi && !found; yb += kScanRows) {
-            float4 v[kScanRows][4];
+    // first hit of this row
+    bool hit = false;
+    float first = 0.0f;
 #pragma unroll
-            for (int r = 0; r < kScanRows; r++)
+    for (int q = 3; q >= 0; q--) {
+        const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int y = yb + r < y_hi ? yb + r : y_hi - 1, x = wx0 + 4 * q;
-                    v[r][q] = x >= 0 ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
-                }
-#pragma unroll
-            for (int r = 0; r < kScanRows; r++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float e[4] = {v[r][q].x, v[r][q].y, v[r][q].z, v[r][q].w};
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int x = wx0 + 4 * q + t;
-                        if (!found && yb + r < y_hi && x >= x_lo && x < x_hi && (double)e[t] > 0.01) {
-                            md = e[t];
-                            found = true;
-                        }
-                    }
-                }
+        for (int t = 3; t >= 0; t--) {
+            const int x = wx0 + 4 * q + t;
+            if (row_in && x >= x_lo && x < x_hi && (double)e[t] > 0.01) { hit = true; first = e[t]; }
         }
     }
-    if (!live) return;
+    // first row with a hit among the 16 lanes of this seed
+    const unsigned long long m = __ballot(hit);
+    const unsigned rows = (unsigned)(m >> (lane & ~(kInitLanes - 1))) & 0xffffu;
+    const int src = (lane & ~(kInitLanes - 1)) + (rows ? __ffs((int)rows) - 1 : 0);
+    const float scanned = __shfl(first, src);
+    if ((double)md < 0.01 && rows) md = scanned;
+    if (!live || r != 0) return;
     c->core[s] = make_float4((float)ix, (float)iy, mi, md);
     c->inv_depth[s] = 1.0 / (double)md;
     c->tmin[s] = -1; // fused = stable = false
@@ -352,6 +360,7 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(cons
     const int gx = s % c->gw, gy = s / c->gw;
     const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
     const int t_self = c->tmin[s];
+    const float4 old = c->core[s]; // needed only after the sums: issued with the window loads, not behind them
     float *dl = s_depth[wv], *lt = s_term[wv];
     stamp(c, sweep, s, 1, lane);
     int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
@@ -412,11 +421,13 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(cons
     wave_lds_sync();
     const float fn = (float)cnt;
     const float mi = (float)si / fn, mx = (float)sx / fn, my = (float)sy / fn;
-    const float4 old = c->core[s];
     const float moved = fabsf(old.z - mi) + fabsf(old.x - mx) + fabsf(old.y - my);
     const int stable = (double)moved < 0.2 ? 1 : 0;
     stamp(c, sweep, s, 3, lane);
     float md = 0.0f;
+    // The kernel ends with its slowest wave, and that is a wave with a long list (its ordered sums are serial chains
+    // of nd adds, up to six of them): let it issue ahead of the short ones sharing its SIMD.
+    wave_priority(nd);
     if (nd > 0) {
         // FF.cpp:530-556.  The loop-carried part of a Huber-Newton pass is only the ordered fp32 sum of
         // the per-element terms; residuals and their classification are computed lane-parallel.
@@ -480,70 +491,33 @@ __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, int s
 }
 
 // ------------------------------------------------------------------------------ seed planes
-// One wave per seed: gather the member pixels with valid depth (window row-major order), keep the
-// depth inliers, average their forward-difference normals, refine a plane by 5 Huber-weighted
-// Gauss-Newton steps and derive position / view angle / size.  Back-projections and pixel normals
-// are recomputed from the depth plane (the reference's 36 B/pixel space_map and norm_map never
-// exist in memory).  Every order-sensitive sum runs in the reference's order, but only the adds are
-// serial: operands are produced lane-parallel, parked in LDS as structure-of-arrays columns and
-// block-fetched.  The 16 Hessian + 4 Jacobian double accumulators of a Gauss-Newton step are
-// independent ordered sums, so 20 lanes each carry one:
+// calculate_spaces / calculate_pixels_norms / calculate_sp_depth_norms + get_huber_norm (FF.cpp:644-712, 792-914,
+// 104-188) in two kernels.
+//
+// k_seed_points, one wave per seed: gather the member pixels with valid depth (window row-major order), keep the
+// depth inliers, recompute their back-projections and forward-difference normals from the depth plane (the
+// reference's 36 B/pixel space_map and norm_map never exist in memory), sum normals and points in the reference's
+// order and hand the centred inlier points to the fit.  Every order-sensitive sum runs in the reference's order,
+// but only the adds are serial: operands are produced lane-parallel, parked in LDS as structure-of-arrays columns
+// and block-fetched; the six fp32 sums are six lanes.
+//
+// k_seed_fit, FOUR seeds per wave: the 5 Huber-weighted Gauss-Newton steps.  A step's 10 + 4 double accumulators
+// (the Hessian is symmetric: H(a,b) and H(b,a) add the same products) are independent ordered sums,
 //     H(a,b) += (double)((2*p_a)*p_b),  J(a) += (double)((2*r)*p_a)   (p_3 = 1; core residuals)
 //     J(a)   += +-hr*(double)p_a                                      (Huber tails)
-// i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}.
-constexpr int kCols = 6; // LDS columns per wave, reused across phases:
+// i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}: 14 lanes of a 16-lane group
+// each carry one, so four seeds fill the wave where one seed used 20 of 64 lanes (the Gauss-Newton steps were 60 %
+// of the one-kernel form's time).  The 4x4 solve is one lane per 2x2 determinant / adjugate entry, again per group.
+constexpr int kCols = 6; // LDS columns per wave of k_seed_points, reused across phases:
 //   gather / inlier phase:  depth list | packed xy | -       | n0       | n1   | n2
 //   sums phase:             p0         | p1        | p2      | n0       | n1   | n2
-//   Gauss-Newton phase:     p0         | p1        | p2      | residual | ones | solver scratch
 // (p0/p1 overwrite the depth/xy lists in place: a chunk's 64 entries are read before its compacted
 // entries, which land at or below the same indices, are written)
 // column stride: 260 floats shifts successive columns by 4 banks, so that lanes streaming different
 // columns at the same element offset (ds_read_b128) do not collide
 constexpr int kColStride = kWin * kWin + 4;
 
-// Ordered double sum of one accumulator over the (padded) inlier list.  Blocks of 8 whose residuals are
-// all in the Huber core take the plain path.  In a block with outliers every element adds
-//     (double)(X*Y) * scale,   scale = 1 for a core element, else hr/2 in a Jacobian lane and 0 in a Hessian lane,
-// where the residual column holds +-1 instead of r for an upper / lower tail element (0 for a NaN residual): the
-// tail term +-(hr/2)*(double)Y of a Jacobian lane is (double)(+-1*Y) * (hr/2) exactly, a core term times 1.0 is
-// itself, and a Hessian lane adds +-0.  Branch-free and without per-element class logic; checked against the
-// three-way form on 8 M random elements on the host.
-// Scaling by two commutes with every rounding, so the sums are carried halved: a core term is
-// (double)(X*Y) instead of (double)((2*X)*Y), a tail term +-(hr/2)*(double)Y, and the result is doubled
-// once at the end -- bit-identical (no overflow / underflow anywhere near these magnitudes), one multiply
-// less per element.
-__device__ __forceinline__ double gn_ordered_sum(const float *xc, const float *yc, int m, const unsigned long long noncore[4],
-                                                 bool is_j, double hr) {
-    double acc = 0.0;
-    const double k_lane = is_j ? 0.5 * hr : 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int lim = m - k * 64 < 64 ? m - k * 64 : 64;
-        if (lim <= 0) break;
-        for (int j = 0; j < lim; j += 8) { // 8 at a time here: two operand columns, register budget
-            const int b = k * 64 + j;
-            const float4 xa = *reinterpret_cast<const float4 *>(xc + b), xb = *reinterpret_cast<const float4 *>(xc + b + 4);
-            const float4 ya = *reinterpret_cast<const float4 *>(yc + b), yb = *reinterpret_cast<const float4 *>(yc + b + 4);
-            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
-            const unsigned n8 = (unsigned)(noncore[k] >> j) & 0xffu;
-            if (n8 == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) acc += (double)(xs[q] * ys[q]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const double v = (double)(xs[q] * ys[q]);
-                    const double scale = ((n8 >> q) & 1u) ? k_lane : 1.0;
-                    acc += v * scale;
-                }
-            }
-        }
-    }
-    return 2.0 * acc;
-}
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_seed_planes(const DeviceCtx ctx) {
+__global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx) {
     const DeviceCtx *__restrict__ c = &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -556,13 +530,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const Intrinsics K = c->k;
     const double hr = c->huber;
     const float4 core = c->core[s];
-    const int is_stable = c->tmin[s] == kIntMax ? 1 : 0;
     const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
     float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2];
     float *N0 = s_col[wv][3], *N1 = s_col[wv][4], *N2 = s_col[wv][5];
-    float *ld = P0, *R = N0, *ONE = N1;
+    float *ld = P0;
     int *lxy = reinterpret_cast<int *>(P1);
-    double *solver = reinterpret_cast<double *>(N2); // [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
 
     // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
     int n = 0;
@@ -603,18 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     wave_lds_sync();
     stamp(c, 3, s, 1, lane);
 
-    dsm_seed out;
-    out.x = core.x; out.y = core.y;
-    out.size = 0; out.norm_x = out.norm_y = out.norm_z = 0;
-    out.posi_x = out.posi_y = out.posi_z = 0;
-    out.view_cos = 0;
-    out.mean_depth = core.w;
-    out.mean_intensity = core.z;
-    out.fused = 0;
-    out.stable = (uint8_t)is_stable;
-    out.pad_[0] = out.pad_[1] = 0;
-    out.min_eigen_value = out.max_eigen_value = 0;
-
+    int m_fit = 0; // inliers handed to the fit; 0: the seed keeps its defaults
+    wave_priority(n); // long lists first: they are the kernel's critical path
     if (n >= 16) { // FF.cpp:841
         // ---- depth inliers: their pixel normals and back-projected points, in order (FF.cpp:846-861)
         const float md = core.w;
@@ -648,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
             m_in += __popcll(m);
         }
-        // pad every column the ordered sums stream to a multiple of 8 with +0.0f (see ordered_sum)
+        // pad every column the ordered sums stream to a multiple of 16 with +0.0f (see ordered_sum)
         wave_lds_sync();
         pad_column(P0, m_in, lane); pad_column(P1, m_in, lane); pad_column(P2, m_in, lane);
         pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
@@ -658,113 +620,321 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             // sequential fp32 sums, FF.cpp:852-857 and 111-116
             // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
             const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in);
-            float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2), nb = 0;
+            float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2);
             float mx = __shfl(part, 3), my = __shfl(part, 4), mz = __shfl(part, 5);
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
             nx = nx / len; ny = ny / len; nz = nz / len;
             mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
-            wave_lds_sync();
-            float q0[4], q1[4], q2[4]; // this lane's (centred) points, FF.cpp:121-126
+            // centred points, FF.cpp:121-126
+            float *pts = c->gn_pts + (int64_t)s * 3 * kGnCap;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int i = k * 64 + lane;
-                q0[k] = q1[k] = q2[k] = 0.0f;
                 if (i < m_in) {
-                    q0[k] = P0[i] - mx; q1[k] = P1[i] - my; q2[k] = P2[i] - mz;
-                    P0[i] = q0[k]; P1[i] = q1[k]; P2[i] = q2[k];
-                    ONE[i] = 1.0f; // the normal columns are dead from here on
+                    pts[i] = P0[i] - mx;
+                    pts[kGnCap + i] = P1[i] - my;
+                    pts[2 * kGnCap + i] = P2[i] - mz;
                 }
             }
-            pad_column(ONE, m_in, lane);
-            pad_column(R, m_in, lane);
-            // per-lane rows of the tabled 4x4 inverse (dsm_math.h, kInv4)
-            int d2[4] = {0, 0, 0, 0}, oe[7] = {0, 0, 0, 0, 0, 0, 1};
-            if (lane < 12)
+            if (lane == 0) {
+                GnHeader hd;
+                hd.m_in = m_in;
+                hd.nx = nx; hd.ny = ny; hd.nz = nz;
+                hd.mx = mx; hd.my = my; hd.mz = mz;
+                hd.far2 = far2;
+                c->gn_hdr[s] = hd;
+            }
+            m_fit = m_in;
+        }
+    }
+    if (m_fit == 0 && lane == 0) c->gn_hdr[s].m_in = 0;
+    stamp(c, 3, s, 5, lane);
+    if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
+}
+
+// ---- the fit: four seeds per wave, sixteen lanes per seed
+// LDS columns per seed: p0 | p1 | p2 | ones | residual, padded with +0.0f up to the longest list of the four (a
+// running sum that starts at +0.0 stays bit-identical when +0.0 is added, and a padded element's product is +0.0).
+constexpr int kFitSeeds = 4, kFitLanes = 16, kFitCols = 5;
+constexpr int kFitStride = kGnCap + 4; // 236 floats: successive columns 16 B x 59 apart -> shifted by 11 x 16 B mod 256
+// accumulator of lane gl of a group: (X column, Y column); columns 0..2 = p, 3 = ones, 4 = residual.
+// gl 0..9 = H(a,b), a <= b; gl 10..13 = J(a); gl 14, 15 idle (they stream ones x ones and are ignored)
+__constant__ const signed char kFitX[16] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 4, 4, 4, 4, 3, 3};
+__constant__ const signed char kFitY[16] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3, 0, 1, 2, 3, 3, 3};
+
+// Ordered double sum of this lane's accumulator over the padded lists (m8 = longest of the four, rounded up to 8).
+// Blocks of 8 whose residuals are in the Huber core for all four seeds take the plain path.  Otherwise every element
+// adds (double)(X*Y) * scale, scale = 1 for a core element, else hr/2 in a Jacobian lane and 0 in a Hessian lane,
+// where the residual column holds +-1 instead of r for an upper / lower tail element (0 for a NaN residual): the
+// tail term +-(hr/2)*(double)Y of a Jacobian lane is (double)(+-1*Y) * (hr/2) exactly, a core term times 1.0 is
+// itself, and a Hessian lane adds +-0.  Branch-free and without per-element class logic; checked against the
+// three-way form on 8 M random elements on the host.
+// Scaling by two commutes with every rounding, so the sums are carried halved: a core term is (double)(X*Y)
+// instead of (double)((2*X)*Y), a tail term +-(hr/2)*(double)Y, and the result is doubled once at the end --
+// bit-identical (no overflow / underflow anywhere near these magnitudes), one multiply less per element.
+// all four seeds' residuals in the Huber core (the usual case after the first step): no masks, and the next block's
+// operands are fetched while this block's adds run -- a wave of this kernel has a SIMD almost to itself, so the LDS
+// latency is not hidden by other waves
+__device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const float *yc, int m8) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(xc), *y4 = reinterpret_cast<const float4 *>(yc);
+    float4 xa = x4[0], xb = x4[1], ya = y4[0], yb = y4[1];
+    double acc = 0.0;
+    for (int b = 8; b <= m8; b += 8) {
+        const int nb = b < m8 ? b >> 2 : 0; // (the last round re-reads block 0 and drops it)
+        const float4 pxa = x4[nb], pxb = x4[nb + 1], pya = y4[nb], pyb = y4[nb + 1];
+        acc += (double)(xa.x * ya.x); acc += (double)(xa.y * ya.y); acc += (double)(xa.z * ya.z); acc += (double)(xa.w * ya.w);
+        acc += (double)(xb.x * yb.x); acc += (double)(xb.y * yb.y); acc += (double)(xb.z * yb.z); acc += (double)(xb.w * yb.w);
+        xa = pxa; xb = pxb; ya = pya; yb = pyb;
+    }
+    return 2.0 * acc;
+}
+
+__device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *yc, int m8, const unsigned long long noncore[4],
+                                                  bool is_j, double hr) {
+    if (__ballot((noncore[0] | noncore[1] | noncore[2] | noncore[3]) != 0) == 0) return fit_ordered_sum_core(xc, yc, m8);
+    double acc = 0.0;
+    const double k_lane = is_j ? 0.5 * hr : 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) d2[q] = kInv4.det2[lane][q];
-            if (lane < 16)
+    for (int k = 0; k < 4; k++) {
+        const int lim = m8 - k * 64 < 64 ? m8 - k * 64 : 64;
+        if (lim <= 0) break;
+        for (int j = 0; j < lim; j += 8) { // 8 at a time: two operand columns, register budget
+            const int b = k * 64 + j;
+            const float4 xa = *reinterpret_cast<const float4 *>(xc + b), xb = *reinterpret_cast<const float4 *>(xc + b + 4);
+            const float4 ya = *reinterpret_cast<const float4 *>(yc + b), yb = *reinterpret_cast<const float4 *>(yc + b + 4);
+            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            const unsigned n8 = (unsigned)(noncore[k] >> j) & 0xffu; // this lane's seed
+            if (__ballot(n8 != 0) == 0) {
 #pragma unroll
-                for (int q = 0; q < 7; q++) oe[q] = kInv4.out[lane][q];
-            double *SA = solver, *SD = solver + 16, *SO = solver + 28, *SJ = solver + 44, *SU = solver + 48;
-            stamp(c, 3, s, 3, lane);
-            // operand columns of this lane's accumulator
-            const bool is_j = lane >= 16;
-            const int ta = lane < 16 ? (lane & 3) : ((lane - 16) & 3), tb = (lane >> 2) & 3;
-            const int xs = is_j ? 4 : ta, ys = is_j ? ta : tb; // 0..2 = p, 3 = ones, 4 = r
-            const float *xc = xs == 0 ? P0 : xs == 1 ? P1 : xs == 2 ? P2 : xs == 3 ? ONE : R;
-            const float *yc = ys == 0 ? P0 : ys == 1 ? P1 : ys == 2 ? P2 : ONE;
-            const int mk = (m_in + 63) >> 6;
-            for (int it = 0; it < 5; it++) {
-                unsigned long long noncore[4] = {0, 0, 0, 0};
+                for (int q = 0; q < 8; q++) acc += (double)(xs[q] * ys[q]);
+            } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k >= mk) break;
-                    const int i = k * 64 + lane;
-                    const bool valid = i < m_in;
-                    const float r = q0[k] * nx + q1[k] * ny + q2[k] * nz + nb;
-                    const int cls = huber_class(r, hr);
-                    // the residual column carries the tail sign for outliers (see gn_ordered_sum)
-                    if (valid) R[i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
-                    noncore[k] = __ballot(valid && cls != 0);
+                for (int q = 0; q < 8; q++) {
+                    const double v = (double)(xs[q] * ys[q]);
+                    const double scale = ((n8 >> q) & 1u) ? k_lane : 1.0;
+                    acc += v * scale;
+                }
+            }
+        }
+    }
+    return 2.0 * acc;
+}
+
+__global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
+    const DeviceCtx *__restrict__ c = &ctx;
+    __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][kFitStride];
+    __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
+    const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
+    const int S = c->n_seed;
+    const int n_groups = (S + kFitSeeds - 1) / kFitSeeds;
+    const int s0 = (n_groups - 1 - (int)blockIdx.x) * kFitSeeds; // bottom rows (long lists) first, see seed_of_block
+    const int s = s0 + g;
+    const bool live = s < S;
+    stamp(c, 4, s0, 0, lane);
+    const FrameParams &fp = frame_params(c);
+    const Intrinsics K = c->k;
+    const double hr = c->huber;
+    GnHeader hd;
+    hd.m_in = 0;
+    float4 core = make_float4(0, 0, 0, 0);
+    int is_stable = 0;
+    if (live) {
+        hd = c->gn_hdr[s];
+        core = c->core[s];
+        is_stable = c->tmin[s] == kIntMax ? 1 : 0;
+    }
+    // the first 64 points of every list are fetched before the list lengths are known (one dependent round trip
+    // less for the half of the groups whose lists are no longer than that; a kernel starts with a cold L2)
+    float4 head[kFitSeeds][3];
+#pragma unroll
+    for (int q = 0; q < kFitSeeds; q++) {
+        const float *pts = c->gn_pts + (int64_t)(s0 + q < S ? s0 + q : S - 1) * 3 * kGnCap;
+#pragma unroll
+        for (int col = 0; col < 3; col++)
+            head[q][col] = lane < 16 ? *reinterpret_cast<const float4 *>(pts + col * kGnCap + lane * 4) : make_float4(0, 0, 0, 0);
+    }
+    const int m = hd.m_in;
+    int mg[kFitSeeds];
+#pragma unroll
+    for (int q = 0; q < kFitSeeds; q++) mg[q] = __builtin_amdgcn_readlane(m, q * kFitLanes);
+    int m_max = mg[0];
+#pragma unroll
+    for (int q = 1; q < kFitSeeds; q++) m_max = mg[q] > m_max ? mg[q] : m_max;
+    const int m8 = (m_max + 7) & ~7;
+    float nx = hd.nx, ny = hd.ny, nz = hd.nz, nb = 0.0f;
+    stamp(c, 4, s0, 1, lane);
+
+    if (m_max > 0) {
+        // ---- lists into LDS: p columns from k_seed_points' hand-off, ones, zeroed residuals, all padded to m8
+#pragma unroll
+        for (int q = 0; q < kFitSeeds; q++) {
+            const float *pts = c->gn_pts + (int64_t)(s0 + q < S ? s0 + q : S - 1) * 3 * kGnCap;
+            const int i4 = lane * 4; // m8 <= 232: one 16-byte chunk per lane and column
+            if (i4 < m8) {
+#pragma unroll
+                for (int col = 0; col < 3; col++) {
+                    float4 v = head[q][col];
+                    if (i4 >= 64) v = i4 < mg[q] ? *reinterpret_cast<const float4 *>(pts + col * kGnCap + i4) : make_float4(0, 0, 0, 0);
+                    if (i4 >= mg[q]) v.x = 0.0f;
+                    if (i4 + 1 >= mg[q]) v.y = 0.0f;
+                    if (i4 + 2 >= mg[q]) v.z = 0.0f;
+                    if (i4 + 3 >= mg[q]) v.w = 0.0f;
+                    *reinterpret_cast<float4 *>(&s_col[q][col][i4]) = v;
+                }
+                const float4 one = make_float4(i4 < mg[q] ? 1.0f : 0.0f, i4 + 1 < mg[q] ? 1.0f : 0.0f, i4 + 2 < mg[q] ? 1.0f : 0.0f,
+                                               i4 + 3 < mg[q] ? 1.0f : 0.0f);
+                *reinterpret_cast<float4 *>(&s_col[q][3][i4]) = one;
+                *reinterpret_cast<float4 *>(&s_col[q][4][i4]) = make_float4(0, 0, 0, 0);
+            }
+        }
+        // per-lane rows of the tabled 4x4 inverse (dsm_math.h, kInv4)
+        int d2[4] = {0, 0, 0, 0}, oe[7] = {0, 0, 0, 0, 0, 0, 1};
+        if (gl < 12)
+#pragma unroll
+            for (int q = 0; q < 4; q++) d2[q] = kInv4.det2[gl][q];
+#pragma unroll
+        for (int q = 0; q < 7; q++) oe[q] = kInv4.out[gl][q];
+        double *SA = s_solver[g], *SD = SA + 16, *SO = SA + 28, *SJ = SA + 44, *SU = SA + 48;
+        const int xs = kFitX[gl], ys = kFitY[gl];
+        const bool is_j = xs == 4;
+        const float *xc = s_col[g][xs], *yc = s_col[g][ys];
+        wave_lds_sync();
+        // this lane's points of every list (element k*64+lane of seed q), for the residuals
+        float pq[kFitSeeds][4][3];
+#pragma unroll
+        for (int q = 0; q < kFitSeeds; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = k * 64 + lane;
+#pragma unroll
+                for (int col = 0; col < 3; col++) pq[q][k][col] = (k * 64 < mg[q] && i < m8) ? s_col[q][col][i] : 0.0f;
+            }
+        stamp(c, 4, s0, 2, lane);
+        unsigned long long h_masks[4] = {0, 0, 0, 0}; // class masks (this lane's seed) the cached inverse was built from
+        for (int it = 0; it < 5; it++) {
+            if (it == 1) stamp(c, 4, s0, 3, lane);
+            // residuals and Huber classes of every seed's list, lane-parallel; the class masks of a seed stay with its lanes
+            unsigned long long noncore[4] = {0, 0, 0, 0};
+            float pn[kFitSeeds][4]; // every seed's plane, wave-uniform
+#pragma unroll
+            for (int q = 0; q < kFitSeeds; q++) {
+                pn[q][0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nx), q * kFitLanes));
+                pn[q][1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ny), q * kFitLanes));
+                pn[q][2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nz), q * kFitLanes));
+                pn[q][3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nb), q * kFitLanes));
+            }
+            // elements 0..63 of all four lists without a branch in between: four independent instruction streams for
+            // the scheduler to interleave (a wave of this kernel has few neighbours to hide its latencies behind)
+#pragma unroll
+            for (int q = 0; q < kFitSeeds; q++) {
+                const bool valid = lane < mg[q];
+                const float r = pq[q][0][0] * pn[q][0] + pq[q][0][1] * pn[q][1] + pq[q][0][2] * pn[q][2] + pn[q][3];
+                const int cls = huber_class(r, hr);
+                // the residual column carries the tail sign for outliers (see fit_ordered_sum)
+                if (valid) s_col[q][4][lane] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
+                const unsigned long long mask = __ballot(valid && cls != 0);
+                if (g == q) noncore[0] = mask;
+            }
+#pragma unroll
+            for (int q = 0; q < kFitSeeds; q++) {
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    if (k * 64 < mg[q]) { // wave-uniform
+                        const int i = k * 64 + lane;
+                        const bool valid = i < mg[q];
+                        const float r = pq[q][k][0] * pn[q][0] + pq[q][k][1] * pn[q][1] + pq[q][k][2] * pn[q][2] + pn[q][3];
+                        const int cls = huber_class(r, hr);
+                        if (valid) s_col[q][4][i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
+                        const unsigned long long mask = __ballot(valid && cls != 0);
+                        if (g == q) noncore[k] = mask;
+                    }
+                }
+            }
+            wave_lds_sync();
+            const double acc = fit_ordered_sum(xc, yc, m8, noncore, is_j, hr);
+            // The Hessian sums read nothing but the points and which elements are in the Huber core: while the class
+            // masks of all four seeds stay what they were when H was last summed (from the second step on they are
+            // normally all-core), H, its damped inverse and the determinant are bit for bit the same, and the
+            // inverse still sits in LDS: only J is new.
+            bool same = it > 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) same = same && noncore[k] == h_masks[k];
+            const bool reuse_inverse = __ballot(!same) == 0;
+            if (gl >= 10 && gl < 14) SJ[gl - 10] = acc;
+            if (!reuse_inverse) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) h_masks[k] = noncore[k];
+                // damped solve, FF.cpp:172-180: one lane per 2x2 determinant, per adjugate entry, per row -- per seed
+                if (gl < 10) {
+                    const double v = xs == ys ? acc + 5 : acc; // +5 on the diagonal
+                    SA[ys * 4 + xs] = v;
+                    SA[xs * 4 + ys] = v;
                 }
                 wave_lds_sync();
-                const double acc = gn_ordered_sum(xc, yc, m_in, noncore, is_j, hr);
-                wave_lds_sync();
-                // damped solve, FF.cpp:172-180: one lane per 2x2 determinant, per adjugate entry, per row
-                if (lane < 16) SA[lane] = (lane % 5 == 0) ? acc + 5 : acc; // +5 on the diagonal
-                else if (lane < 20) SJ[lane - 16] = acc;
-                wave_lds_sync();
-                if (lane < 12) SD[lane] = SA[d2[0]] * SA[d2[1]] - SA[d2[2]] * SA[d2[3]];
+                if (gl < 12) SD[gl] = SA[d2[0]] * SA[d2[1]] - SA[d2[2]] * SA[d2[3]];
                 wave_lds_sync();
                 double Dv[12];
 #pragma unroll
                 for (int t = 0; t < 12; t++) Dv[t] = SD[t];
                 const double inv_det = 1.0 / inv4_det(Dv);
-                if (lane < 16) {
-                    const double g = (double)oe[6];
-                    const double t1 = g * (SA[oe[0]] * SD[oe[1]]), t2 = g * (SA[oe[2]] * SD[oe[3]]), t3 = g * (SA[oe[4]] * SD[oe[5]]);
-                    SO[lane] = ((t1 - t2) + t3) * inv_det;
-                }
-                wave_lds_sync();
-                if (lane < 4) SU[lane] = ((SO[lane] * SJ[0] + SO[4 + lane] * SJ[1]) + SO[8 + lane] * SJ[2]) + SO[12 + lane] * SJ[3];
-                wave_lds_sync();
-                nx = (float)((double)nx - SU[0]);
-                ny = (float)((double)ny - SU[1]);
-                nz = (float)((double)nz - SU[2]);
-                nb = (float)((double)nb - SU[3]);
-                wave_lds_sync();
+                const double sg = (double)oe[6];
+                const double t1 = sg * (SA[oe[0]] * SD[oe[1]]), t2 = sg * (SA[oe[2]] * SD[oe[3]]), t3 = sg * (SA[oe[4]] * SD[oe[5]]);
+                SO[gl] = ((t1 - t2) + t3) * inv_det;
             }
-            stamp(c, 3, s, 4, lane);
-            plane_finish(nx, ny, nz, nb, mx, my, mz);
-            const SeedGeom g = seed_geometry(K, core.x, core.y, md, nx, ny, nz, nb);
-            out.norm_x = g.nx; out.norm_y = g.ny; out.norm_z = g.nz;
-            out.posi_x = g.px; out.posi_y = g.py; out.posi_z = g.pz;
-            out.mean_depth = g.mean_depth;
-            out.view_cos = g.view_cos;
-            out.size = sqrtf(far2);
+            wave_lds_sync();
+            if (gl < 4) SU[gl] = ((SO[gl] * SJ[0] + SO[4 + gl] * SJ[1]) + SO[8 + gl] * SJ[2]) + SO[12 + gl] * SJ[3];
+            wave_lds_sync();
+            nx = (float)((double)nx - SU[0]);
+            ny = (float)((double)ny - SU[1]);
+            nz = (float)((double)nz - SU[2]);
+            nb = (float)((double)nb - SU[3]);
+            wave_lds_sync();
         }
     }
-    stamp(c, 3, s, 5, lane);
-    if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
-    if (lane == 0) {
-        c->seeds[s] = out;
-        // initialize_surfels, FF.cpp:315-361, up to the `fused` test (k_frame_tail applies it)
-        SeedView sd;
-        sd.size = out.size; sd.nx = out.norm_x; sd.ny = out.norm_y; sd.nz = out.norm_z;
-        sd.px = out.posi_x; sd.py = out.posi_y; sd.pz = out.posi_z;
-        sd.view_cos = out.view_cos; sd.mean_depth = out.mean_depth; sd.mean_intensity = out.mean_intensity;
-        const bool ok = seed_spawns(sd, false);
-        if (ok) {
-            const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
-            dsm_surfel o;
-            o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
-            o.size = e.size; o.color = e.color; o.weight = e.weight;
-            o.update_times = e.update_times; o.last_update = e.last_update;
-            c->spawn_rec[s] = o;
-        }
-        c->spawn_ok[s] = ok ? 1 : 0;
-        c->fused_flag[s] = 0;
+
+    stamp(c, 4, s0, 4, lane);
+    if (c->stamps && lane == 0) c->stamps[((int64_t)4 * c->n_seed + s0) * 8 + 7] = m_max;
+    // ---- seed record and the surfel it would create: one lane per seed
+    if (!live || gl != 0) return;
+    dsm_seed out;
+    out.x = core.x; out.y = core.y;
+    out.size = 0; out.norm_x = out.norm_y = out.norm_z = 0;
+    out.posi_x = out.posi_y = out.posi_z = 0;
+    out.view_cos = 0;
+    out.mean_depth = core.w;
+    out.mean_intensity = core.z;
+    out.fused = 0;
+    out.stable = (uint8_t)is_stable;
+    out.pad_[0] = out.pad_[1] = 0;
+    out.min_eigen_value = out.max_eigen_value = 0;
+    if (m > 0) {
+        plane_finish(nx, ny, nz, nb, hd.mx, hd.my, hd.mz);
+        const SeedGeom sg = seed_geometry(K, core.x, core.y, core.w, nx, ny, nz, nb);
+        out.norm_x = sg.nx; out.norm_y = sg.ny; out.norm_z = sg.nz;
+        out.posi_x = sg.px; out.posi_y = sg.py; out.posi_z = sg.pz;
+        out.mean_depth = sg.mean_depth;
+        out.view_cos = sg.view_cos;
+        out.size = sqrtf(hd.far2);
     }
+    c->seeds[s] = out;
+    // initialize_surfels, FF.cpp:315-361, up to the `fused` test (k_frame_tail applies it)
+    SeedView sd;
+    sd.size = out.size; sd.nx = out.norm_x; sd.ny = out.norm_y; sd.nz = out.norm_z;
+    sd.px = out.posi_x; sd.py = out.posi_y; sd.pz = out.posi_z;
+    sd.view_cos = out.view_cos; sd.mean_depth = out.mean_depth; sd.mean_intensity = out.mean_intensity;
+    const bool ok = seed_spawns(sd, false);
+    if (ok) {
+        const Surfel e = spawn_surfel(K, fp.ref_idx, fp.pose, sd);
+        dsm_surfel o;
+        o.px = e.px; o.py = e.py; o.pz = e.pz; o.nx = e.nx; o.ny = e.ny; o.nz = e.nz;
+        o.size = e.size; o.color = e.color; o.weight = e.weight;
+        o.update_times = e.update_times; o.last_update = e.last_update;
+        c->spawn_rec[s] = o;
+    }
+    c->spawn_ok[s] = ok ? 1 : 0;
+    c->fused_flag[s] = 0;
+    if (g == 0) stamp(c, 4, s0, 5, 0);
 }
 
 // ------------------------------------------------------------------------------ fuse surfels
@@ -1218,7 +1388,7 @@ __global__ void k_delay(long long ticks) {
 // ------------------------------------------------------------------------------ launcher
 const char *const kStageNames[kNumStages] = {
     "init_seeds", "assign_0",  "update_seeds_0", "commit_seeds_0", "assign_1",    "resolve_1",    "update_seeds_1", "commit_seeds_1",
-    "assign_2",   "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_planes", "fuse_surfels", "frame_tail",
+    "assign_2",   "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_points", "seed_fit", "fuse_surfels", "frame_tail",
 };
 
 hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
@@ -1248,7 +1418,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
-    hipLaunchStage(k_init_seeds, dim3((S + 63) / 64), dim3(64), 0, st, hc);
+    hipLaunchStage(k_init_seeds, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256), 0, st, hc);
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
@@ -1267,7 +1437,9 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
         hipLaunchStage(k_commit_seeds, g_seed_thr, dim3(256), 0, st, hc, sweep);
         DSM_MARK();
     }
-    hipLaunchStage(k_seed_planes, g_seed_wave, dim3(256), 0, st, hc);
+    hipLaunchStage(k_seed_points, g_seed_wave, dim3(256), 0, st, hc);
+    DSM_MARK();
+    hipLaunchStage(k_seed_fit, dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64), 0, st, hc);
     DSM_MARK();
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;

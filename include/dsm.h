@@ -208,7 +208,7 @@ int dsm_seed_count(const dsm_handle *h);
 /* ---- state-level test taps (poke superpixel state, run single stages) ------------------
  * Stage indices are positions in the frame's kernel sequence: 0 init_seeds, 1 assign_0, 2 update_seeds_0,
  * 3 commit_seeds_0, 4 assign_1, 5 resolve_1, 6 update_seeds_1, 7 commit_seeds_1, 8 assign_2, 9 resolve_2,
- * 10 update_seeds_2, 11 commit_seeds_2, 12 seed_planes, 13 fuse_surfels, 14 frame_tail.  Labels of sweep 0 and
+ * 10 update_seeds_2, 11 commit_seeds_2, 12 seed_points, 13 seed_fit, 14 fuse_surfels, 15 frame_tail.  Labels of sweep 0 and
  * 2 live in buffer 0, of sweep 1 in buffer 1. */
 int dsm_debug_run_stages(dsm_handle *h, int slot, int reference_frame_index, const float *pose16, int first_stage,
                          int last_stage);
@@ -218,8 +218,8 @@ int dsm_debug_set_label_buffer(dsm_handle *h, int which, const int32_t *in);
 int dsm_debug_get_seed_state(dsm_handle *h, float *core4, int32_t *stable);
 int dsm_debug_set_seed_state(dsm_handle *h, const float *core4, const int32_t *stable);
 
-/* debug tap: shader-clock stamps of the phases of the per-seed kernels, [4][n_seed][8] (kernel 0..2 =
- * update_seeds of sweep 0..2, 3 = seed_planes); needs DSM_WAVE_STAMPS=1 in the environment at dsm_create */
+/* debug tap: shader-clock stamps of the phases of the per-seed kernels, [5][n_seed][8] (kernel 0..2 =
+ * update_seeds of sweep 0..2, 3 = seed_points, 4 = seed_fit at the first seed of each group of four); needs DSM_WAVE_STAMPS=1 in the environment at dsm_create */
 int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out);
 
 /* ---- per-kernel timing (hip events on the handle's stream) ----------------------------- */

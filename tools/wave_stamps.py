@@ -20,8 +20,8 @@ for t, img, dep, pose, ref in frames:
     ff.fuse_frame_resident(t, ref, pose)
 ff.synchronize()
 st = ff.debug_wave_stamps()
-names = ["update_seeds_0", "update_seeds_1", "update_seeds_2", "seed_planes"]
-for k in range(4):
+names = ["update_seeds_0", "update_seeds_1", "update_seeds_2", "seed_points", "seed_fit"]
+for k in range(5):
     a = st[k]
     live = a[:, 5] > 0
     if not live.any():
