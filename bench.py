@@ -1,16 +1,19 @@
 #!/usr/bin/env python
 """Benchmark of the per-frame surfel-fusion hot path (BASELINE.json: depth frames fused/sec @ 1226x370).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B] [--frames-per-step F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): BASELINE configs[1] -- synthetic KITTI-shaped replay, 1226x370, one frame
 = SLIC superpixels + normals/plane fit + projective fuse + new surfels + map compaction
 (FusionFunctions::fuse_initialize_map + SurfelMap::fuse_map), inputs resident in HBM.  Each rank owns
-one GPU and replays B independent subsequences on B handles (streams); one STEP advances every
-subsequence of the rank by one frame, so a step fuses B frames per GPU.  There is no collective on the
+one GPU and replays B independent subsequences (B handles, B different synthetic scenes); one STEP advances
+every subsequence of the rank by F frames, so a step fuses B*F frames per GPU.  There is no collective on the
 data path (weak scaling: work per GPU is fixed); the final clouds are merged once, outside the timed
 region, with an RCCL all-gather.
+
+The CPU baseline replays subsequence 0 of rank 0 from its first frame and is timed over the SAME frame
+indices, against the same map state, as the GPU's timed region (a bounded prefix of it when the region is long).
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,16 +33,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def stage_alg_bytes(stage, cam, n_seed, m_avg, k_avg):
+def stage_alg_bytes(stage, n, n_seed, m_avg, k_avg):
     """Algorithmic bytes one launch of `stage` must move: planes it has to read or
-    write once, nothing for re-reads of overlapping windows or intermediates."""
-    n = cam.width * cam.height
+    write once, nothing for re-reads of overlapping windows or intermediates handed between kernels."""
     base = stage.rstrip("_012")
     if base == "assign":
         first = stage.endswith("_0")
         return n * (1 + 4) + n * 4 + (0 if first else n * 4) + n_seed * 24
-    if base == "apply":
-        return n * 4 * 3
     if base == "update_seeds":
         return n * (4 + 1 + 4) + n_seed * 32
     if base == "seed_points":  # labels + depth in, per-seed state in (the centred points handed to the fit are an intermediate)
@@ -48,32 +48,51 @@ def stage_alg_bytes(stage, cam, n_seed, m_avg, k_avg):
         return n_seed * (60 + 44 + 2)
     if base == "fuse_surfels":
         return m_avg * 88
-    if base == "new_surfels":
-        return n_seed * 60 + k_avg * 44
-    if base == "compact":
-        return k_avg * 88
-    if base == "hole_scan":
-        return m_avg / 8
+    if base == "frame_tail":
+        return n_seed * 2 + k_avg * (4 + 88) + m_avg / 8
     return n_seed * 16
 
 
+# stage (position in the frame's launch sequence) -> kernel function, as rocprofv3 names them
+KERNEL_OF_STAGE = {
+    "init_seeds": "k_init_seeds", "assign_0": "k_assign<true>", "assign_1": "k_assign<false>", "assign_2": "k_assign<false>",
+    "resolve_1": "k_resolve", "resolve_2": "k_resolve",
+    "update_seeds_0": "k_update_seeds<false>", "update_seeds_1": "k_update_seeds<true>", "update_seeds_2": "k_update_seeds<true>",
+    "commit_seeds_0": "k_commit_seeds", "commit_seeds_1": "k_commit_seeds", "commit_seeds_2": "k_commit_seeds",
+    "seed_points": "k_seed_points", "seed_fit": "k_seed_fit", "fuse_surfels": "k_fuse_surfels", "frame_tail": "k_frame_tail",
+}
+
+
 def pmc_traffic(stage):
-    """HBM-side bytes per launch of `stage` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE are collected in separate runs, tools/gpu_pmc.sh; profiles/r01_pmc_traffic.json records
-    them with the calibration used).  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    kernels = json.load(open(path)).get("kernels", {})
-    rec = kernels.get(stage) or kernels.get(stage.rstrip("012").rstrip("_"))
-    return rec["hbm_bytes_per_launch"] if rec else None
+    """HBM-side bytes per launch of `stage` from the committed rocprofv3 --pmc passes of this round (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, tools/gpu_pmc.sh; the JSON records them with the calibration used).
+    Counters cannot be read from inside the run; None when no measurement is on file."""
+    for name in ("r02_pmc_traffic.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        kernels = json.load(open(path)).get("kernels", {})
+        rec = kernels.get(stage)
+        if rec:
+            return rec["hbm_bytes_per_launch"], name
+    return None, None
 
 
-def cpu_baseline(cam, scene, synth, n_warm=20, n_timed=300, budget_s=25.0):
-    """The reference's own fusion_functions.cpp (oracle/_ref, real 10-thread schedule) if its prebuilt
-    library is present, else our C restatement (1 thread), on a bounded sample of the same workload:
-    BASELINE.md §3 -- 20 warm-up frames, then up to 300 timed frames (bounded to ~25 s), whole-sample rate
-    plus median / p10 / p90 of the per-frame rates."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cam, scene, rendered, period, lo, hi, budget_s=25.0):
+    """The reference's own fusion_functions.cpp (oracle/_ref, real 10-thread schedule) if its prebuilt library is
+    present, else our C restatement (1 thread).  Replays the subsequence from frame 0 (untimed up to `lo`: that builds
+    the map state the GPU's timed region starts from) and times frames [lo, hi) -- the GPU's timed frame indices --
+    stopping early once `budget_s` of timed work is spent.  Also returns the measured K and M of those frames."""
     from oracle import bindings as ob
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
@@ -82,55 +101,100 @@ def cpu_baseline(cam, scene, synth, n_warm=20, n_timed=300, budget_s=25.0):
     else:
         orc, kind, cores = ob.PortOracle(cam), "port", 1
     local = np.zeros(0, ob.SURFEL_DTYPE)
-    per_frame = []
+    per_frame, news, sizes = [], [], []
     devnull = os.open(os.devnull, os.O_WRONLY)
     saved = os.dup(1)
     os.dup2(devnull, 1)  # the reference prints timers on every frame
     try:
-        t_start = time.perf_counter()
-        for t, img, dep, pose, ref in synth.sequence(cam, scene, n_warm + n_timed):
+        spent = 0.0
+        for t in range(hi):
+            img, dep = rendered[t % period]
             t0 = time.perf_counter()
-            local, _ = orc.fuse_map(ref, img, dep, pose, local)
-            if t >= n_warm:
-                per_frame.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > budget_s and len(per_frame) >= 20:
-                break
+            local, k = orc.fuse_map(t // 5, img, dep, scene.pose(t), local)
+            dt = time.perf_counter() - t0
+            if t >= lo:
+                per_frame.append(dt)
+                news.append(k)
+                sizes.append(len(local))
+                spent += dt
+                if spent > budget_s and len(per_frame) >= 20:
+                    break
     finally:
         os.dup2(saved, 1)
         os.close(devnull)
     pf = np.array(per_frame)
     rates = 1.0 / pf
     return {"value": round(len(pf) / pf.sum(), 2), "unit": "frames/s", "cores": cores, "kind": kind,
-            "host_cpus": os.cpu_count(), "median": round(float(np.median(rates)), 2),
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "median": round(float(np.median(rates)), 2),
             "p10": round(float(np.percentile(rates, 10)), 2), "p90": round(float(np.percentile(rates, 90)), 2),
-            "final_map_surfels": int(len(local)),
-            "sample": f"frames {n_warm}..{n_warm + len(pf) - 1} of the same synthetic 1226x370 sequence after {n_warm} warm-up "
-                      f"frames, fuse_initialize_map + compaction per frame, "
-                      f"{'10 std::threads per stage as in the reference' if kind == 'reference' else 'scalar C restatement'}"}
+            "mean_live_surfels": round(float(np.mean(sizes))), "mean_new_surfels": round(float(np.mean(news)), 1),
+            "sample": f"frames {lo}..{lo + len(pf) - 1} of subsequence 0 (the GPU's timed region is frames {lo}..{hi - 1} of every "
+                      f"subsequence), same map state: the {lo} frames before them replayed untimed; fuse_initialize_map + compaction "
+                      f"per frame, {'10 std::threads per stage as in the reference' if kind == 'reference' else 'scalar C restatement'}"}
+
+
+def event_timer(torch, ff):
+    """HIP events on the handle's own stream (torch.cuda.Event only sees torch's current stream by default)."""
+    stream = torch.cuda.ExternalStream(ff.stream())
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps  # us per call
+    return timed
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSM_BENCH_STREAMS", "8")),
                     help="independent subsequences (handles/streams) per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSM_BENCH_FRAMES_PER_STEP", "32")),
+                    help="frames every subsequence advances per step")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("DSM_BENCH_HOST_THREADS", "4")),
                     help="host threads enqueueing graph replays (each drives streams/threads handles)")
     ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("DSM_BENCH_PIPELINE_DEPTH", "0")),
                     help="frames of one subsequence whose superpixel stages may be in flight (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the legs beside the headline (drop-in, configs 4 and 5, node)")
     args = ap.parse_args()
-
-    import torch
-    from densesurfelmapping_amd import api, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    B, K, W, F = args.streams, args.steps, args.warmup, args.frames_per_step
+    period = 50
+    extras = rank == 0 and world == 1 and not args.no_dropin
+
+    # ---- all synthetic frames first, on worker processes (fresh interpreters, clean environment; cached in /tmp)
+    from densesurfelmapping_amd import synth
+    cam = synth.KITTI_1226
+    n_seed = (cam.width // 8) * (cam.height // 8)
+    n_pix = cam.width * cam.height
+    scenes = [synth.Scene(seed=12345 + 1000 * rank + 17 * b, frames_per_period=period) for b in range(B)]
+    jobs = [(cam, scenes[b], i) for b in range(B) for i in range(period)]
+    cam_v, scene_v = synth.VGA_RGBD, synth.Scene(seed=5, scale=0.12, step=0.05, frames_per_period=30)
+    cam_h, scene_h = synth.FULLHD, synth.Scene(seed=12345, frames_per_period=10)
+    if extras:
+        jobs += [(cam_v, scene_v, i) for i in range(30)] + [(cam_h, scene_h, i) for i in range(10)]
+    workers = max(1, min(48, (os.cpu_count() or 2) // (2 * max(world, 1))))
+    t_r = time.perf_counter()
+    frames_all = synth.render_many(jobs, workers)
+    render_s = time.perf_counter() - t_r
+    rendered = [frames_all[b * period:(b + 1) * period] for b in range(B)]
+    frames_v = frames_all[B * period:B * period + 30] if extras else []
+    frames_h = frames_all[B * period + 30:B * period + 40] if extras else []
+
+    import torch
+    from densesurfelmapping_amd import api
+
     # DSM_BENCH_BACKEND=gloo + DSM_BENCH_ONE_DEVICE=1 run the multi-rank logic on a single GPU (tests only):
     # every rank uses cuda:0 and the collectives run on CPU tensors.
     backend = os.environ.get("DSM_BENCH_BACKEND", "nccl")
@@ -146,26 +210,19 @@ def main():
     coll_dev = f"cuda:{device}" if backend == "nccl" else "cpu"
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
-    cam = synth.KITTI_1226
-    B, K, W = args.streams, args.steps, args.warmup
-    period = 50
-    n_seed = (cam.width // 8) * (cam.height // 8)
-
-    # one scene period of frames per rank (seed differs per rank); the rank's B subsequences replay
-    # the same images into B independent maps
-    scene = synth.Scene(seed=12345 + 1000 * rank, frames_per_period=period)
-    rendered = [synth.render(cam, scene, i)[:2] for i in range(period)]
+    total = (W + K) * F
+    lo_t, hi_t = W * F, total  # frame indices of the timed region, per subsequence
+    capacity = 1 << 21
     handles, plans = [], []
     for b in range(B):
-        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=1 << 21,
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity,
                                              pipeline_depth=args.pipeline_depth or 1)  # B subsequences already fill the queues
-        for i, (img, dep) in enumerate(rendered):
+        for i, (img, dep) in enumerate(rendered[b]):
             ff.frame_upload(i, img, dep)
         ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
-        total = W + K
         slots = [t % period for t in range(total)]
         refs = [t // 5 for t in range(total)]
-        poses = np.stack([scene.pose(t) for t in range(total)])
+        poses = np.stack([scenes[b].pose(t) for t in range(total)])
         plans.append(api.FusionFunctions.pack_replay(slots, refs, poses))
         handles.append(ff)
 
@@ -195,14 +252,14 @@ def main():
             ff.synchronize()
         torch.cuda.synchronize()
 
-    run(0, W)
+    run(0, lo_t)
     sync_all()
     m_start = [ff.map_size() for ff in handles]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(W, W + K)
+    run(lo_t, hi_t)
     sync_all()
     if world > 1:
         dist.barrier()
@@ -229,12 +286,9 @@ def main():
     for ff in handles:  # the extra measurements below run alone on the GPU
         ff.close()
     handles = []
-    frames_total = world * B * K
+    frames_total = world * B * K * F
     fps = frames_total / dt
     m_avg = float(np.mean([(a + b) / 2 for a, b in zip(m_start, m_end)]))
-    k_avg = 1400.0
-    n = cam.width * cam.height
-    b_alg_frame = 9 * n + 60 * n_seed + 88 * m_avg + 44 * k_avg
 
     out = {
         "metric": "depth frames fused/sec @ KITTI 1226x370",
@@ -243,112 +297,174 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: synthetic KITTI-shaped replay 1226x370, full superpixel+normal+"
                                "fuse+compaction HIP path, frames and map resident in HBM",
-                   "subsequences_per_gpu": B, "frames_per_step_per_gpu": B, "host_enqueue_threads": n_thr,
+                   "subsequences_per_gpu": B, "frames_per_subsequence_per_step": F, "frames_per_step_per_gpu": B * F,
+                   "timed_frame_indices": [lo_t, hi_t - 1], "host_enqueue_threads": n_thr,
                    "pipeline_depth": args.pipeline_depth or 1,
                    "host_enqueue_seconds": round(enqueue_s[0], 4), "timed_seconds": round(dt, 4), "scene_period_frames": period,
+                   "scenes": "one synthetic scene per subsequence (seed 12345 + 1000*rank + 17*b)",
+                   "host_render_seconds": round(render_s, 1),
                    "mean_live_surfels": round(m_avg), "final_surfels_all_ranks": merged_total,
                    "parallelism": f"{world} GPU x {B} independent subsequences, all-gather of final cloud only"},
-        "e2e_algorithmic_GBps": round(fps * b_alg_frame / 1e9, 2),
-        "e2e_hbm_frac": round(fps * b_alg_frame / 1e9 / (HBM_PEAK_GBS * world), 5),
     }
 
+    k_avg = None
     if rank == 0 and not args.no_roofline:
-        # per-kernel durations, measured live with HIP events on the handle's own stream (eager replay
-        # of the same workload on a fresh handle; a long delay kernel in front of each frame keeps the
-        # host launch latency out of the intervals)
-        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=1 << 21)
-        for i, (img, dep) in enumerate(rendered):
+        # per-kernel durations, measured live with HIP events on the handle's own stream (eager replay of frames of
+        # the timed region of subsequence 0 on a fresh handle; a long delay kernel in front of each frame keeps the
+        # host launch latency out of the intervals).  K and M of B_alg are measured on the same frames.
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity)
+        for i, (img, dep) in enumerate(rendered[0]):
             ff.frame_upload(i, img, dep)
         ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
-        nt = min(W + K, 120)
-        s, r, p = plans[0][0][:nt], plans[0][1][:nt], plans[0][2][:nt]
-        ff.replay_enqueue(s[:20], r[:20], p[:20])
+        s, r, p = plans[0]
+        ff.replay_enqueue(s[:lo_t], r[:lo_t], p[:lo_t])
         ff.synchronize()
-        m0 = ff.map_size()
-        stages, nfr = ff.replay_timed(s[20:], r[20:], p[20:])
-        m1 = ff.map_size()
-        mt = (m0 + m1) / 2
+        n_ev = min(hi_t - lo_t, 96)
+        stages, nfr = ff.replay_timed(s[lo_t:lo_t + n_ev], r[lo_t:lo_t + n_ev], p[lo_t:lo_t + n_ev])
+        mt, k_avg = ff.timed_mean_local, ff.timed_mean_new
         ovh = ff.event_overhead_ms * 1e3  # an empty event-to-event interval, subtracted from every stage
         per = {k: max(v[0] / max(v[1], 1) * 1e3 - ovh, 0.0) for k, v in stages.items()}  # us per launch
-        dom = max(per, key=per.get)
-        alg = stage_alg_bytes(dom, cam, n_seed, mt, k_avg)
-        achieved = alg / (per[dom] * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
+        # dominant kernel = the kernel FUNCTION with the largest share of a frame's GPU time, as `rocprofv3 --stats`
+        # ranks them (k_update_seeds<true> runs twice per frame, k_assign<false> twice, ...); achieved = algorithmic
+        # bytes of one launch / its average launch duration.  Every stage's own fraction is in kernel_hbm_frac.
+        groups = {}
+        for st_name, us in per.items():
+            groups.setdefault(KERNEL_OF_STAGE.get(st_name, st_name), []).append(st_name)
+        dom_fn = max(groups, key=lambda g: sum(per[x] for x in groups[g]))
+        dom_stages = groups[dom_fn]
+        dom_us = float(np.mean([per[x] for x in dom_stages]))
+        alg = float(np.mean([stage_alg_bytes(x, n_pix, n_seed, mt, k_avg) for x in dom_stages]))
+        achieved = alg / (dom_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(dom_fn)
+        out["roofline"] = {"bound": "hbm", "kernel": dom_fn, "launches_per_frame": len(dom_stages),
+                           "share_of_frame_kernel_time": round(sum(per[x] for x in dom_stages) / sum(per.values()), 3),
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc, separate passes)" if traffic_src else None,
                            "event_overhead_us": round(ovh, 2),
-                           "alg_bytes_per_launch": int(alg), "avg_launch_us": round(per[dom], 2)}
+                           "alg_bytes_per_launch": int(alg), "avg_launch_us": round(dom_us, 2),
+                           "frames_timed": int(nfr), "mean_live_surfels": round(mt), "mean_new_surfels": round(k_avg, 1),
+                           "longest_single_launch": {"stage": max(per, key=per.get), "us": round(max(per.values()), 2),
+                                                     "hbm_frac": round(stage_alg_bytes(max(per, key=per.get), n_pix, n_seed, mt, k_avg)
+                                                                       / (max(per.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}}
         out["kernel_us"] = {k: round(v, 2) for k, v in per.items()}
+        out["kernel_hbm_frac"] = {k: round(stage_alg_bytes(k, n_pix, n_seed, mt, k_avg) / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                                  for k, v in per.items() if v > 0}
         out["frame_kernel_sum_us"] = round(sum(per.values()), 1)
         ksum = sum(per.values()) * 1e-6
-        b_alg_t = 9 * n + 60 * n_seed + 88 * mt + 44 * k_avg
+        b_alg_t = 9 * n_pix + 60 * n_seed + 88 * mt + 44 * k_avg
         out["kernel_time_weighted_hbm_frac"] = round(b_alg_t / ksum / 1e9 / HBM_PEAK_GBS, 5)
         ff.close()
 
-    if rank == 0 and world == 1 and not args.no_dropin:
+    if extras:
         # ONE sequence (BASELINE configs[1] as the reference would replay it): frames are strictly ordered, but
         # only fuse + tail need the map -- the superpixel stages of up to 8 frames run ahead on their own streams
-        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=1 << 21, pipeline_depth=8)
-        for i, (img, dep) in enumerate(rendered):
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity, pipeline_depth=8)
+        for i, (img, dep) in enumerate(rendered[0]):
             ff.frame_upload(i, img, dep)
         ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
         s1, r1, p1 = plans[0]
-        ff.replay_enqueue(s1[:W], r1[:W], p1[:W])
+        ff.replay_enqueue(s1[:lo_t], r1[:lo_t], p1[:lo_t])
         ff.synchronize()
         t_s = time.perf_counter()
-        ff.replay_enqueue(s1[W:W + K], r1[W:W + K], p1[W:W + K])
+        ff.replay_enqueue(s1[lo_t:hi_t], r1[lo_t:hi_t], p1[lo_t:hi_t])
         ff.synchronize()
-        out["single_sequence"] = {"value": round(K / (time.perf_counter() - t_s), 1), "unit": "frames/s", "pipeline_depth": 8,
+        out["single_sequence"] = {"value": round((hi_t - lo_t) / (time.perf_counter() - t_s), 1), "unit": "frames/s", "pipeline_depth": 8,
                                   "note": "one subsequence, one handle: superpixel stages of 8 consecutive frames in flight, "
                                           "fuse + compaction strictly in frame order; same results as the serial order"}
         ff.close()
 
-    if rank == 0 and world == 1 and not args.no_dropin:
+    if extras:
         # the synchronous drop-in call (host buffers in and out over PCIe every frame), for DESIGN.md;
         # never the headline value
-        ff = api.FusionFunctions.from_camera(cam, device=device, surfel_capacity=1 << 21)
+        ff = api.FusionFunctions.from_camera(cam, device=device, surfel_capacity=capacity)
         local = np.zeros(0, api.SURFEL_DTYPE)
-        for t in range(40):
-            local, _ = ff.fuse_map(t // 5, rendered[t % period][0], rendered[t % period][1], scene.pose(t), local)
+        n_d0, n_d1 = 60, 160
+        for t in range(n_d0):
+            local, _ = ff.fuse_map(t // 5, rendered[0][t % period][0], rendered[0][t % period][1], scenes[0].pose(t), local)
         t_d = time.perf_counter()
-        for t in range(40, 70):
-            local, _ = ff.fuse_map(t // 5, rendered[t % period][0], rendered[t % period][1], scene.pose(t), local)
-        out["dropin_pcie_inclusive"] = {"value": round(30 / (time.perf_counter() - t_d), 1), "unit": "frames/s",
+        for t in range(n_d0, n_d1):
+            local, _ = ff.fuse_map(t // 5, rendered[0][t % period][0], rendered[0][t % period][1], scenes[0].pose(t), local)
+        out["dropin_pcie_inclusive"] = {"value": round((n_d1 - n_d0) / (time.perf_counter() - t_d), 1), "unit": "frames/s",
                                         "map_surfels": int(len(local)),
-                                        "note": "dsm_fuse_map with host buffers: frame H2D + map H2D/D2H + sync per frame"}
+                                        "note": "dsm_fuse_map with pageable host buffers (what SurfelMap::fuse_map hands over): frame H2D, "
+                                                "map H2D + D2H and a sync every frame, plus numpy's copy of the returned map"}
         ff.close()
 
-    if rank == 0 and world == 1 and not args.no_dropin:
-        # SURVEY.md §8(f) row 1, BASELINE configs[4] size: loop-closure deformation of a 2 M-surfel resident map
-        # (surfel_map.cpp:750-789), the one purely HBM-bound stage: 88 B per surfel
-        n_w = 2_000_000
+    if extras:
+        # BASELINE configs[4]: 1920x1080 depth stream against >= 2 M live surfels, and the loop-closure deformation
+        # (surfel_map.cpp:750-789).  The big map is the map of a short 1080p replay replicated
+        # with millimetre jitter, so that its surfels project into the frames and take the fusion branch.
+        n_h = (cam_h.width // 8) * (cam_h.height // 8)
+        ff = api.FusionFunctions.from_camera(cam_h, device=device, frame_slots=10, surfel_capacity=2_600_000, pipeline_depth=1)
+        for i, (img, dep) in enumerate(frames_h):
+            ff.frame_upload(i, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        plan_h = api.FusionFunctions.pack_replay([t % 10 for t in range(60)], [t // 5 for t in range(60)],
+                                                 np.stack([scene_h.pose(t % 10) for t in range(60)]))
+        ff.replay_enqueue(plan_h[0][:10], plan_h[1][:10], plan_h[2][:10])
+        base = ff.map_download()
+        rng = np.random.default_rng(0)
+        big = np.tile(base, max(1, -(-2_000_000 // max(len(base), 1))))
+        for f in ("px", "py", "pz"):
+            big[f] += rng.normal(scale=1e-3, size=len(big)).astype(np.float32)
+        big["update_times"] = 9
+        big["last_update"] = 2
+        ff.map_upload(big)
+        ff.replay_enqueue(plan_h[0][10:20], plan_h[1][10:20], plan_h[2][10:20])
+        ff.synchronize()
+        t_h = time.perf_counter()
+        ff.replay_enqueue(plan_h[0][20:40], plan_h[1][20:40], plan_h[2][20:40])
+        ff.synchronize()
+        dt_h = (time.perf_counter() - t_h) / 20
+        st_h, _ = ff.replay_timed(plan_h[0][40:52], plan_h[1][40:52], plan_h[2][40:52])
+        ovh_h = ff.event_overhead_ms * 1e3
+        per_h = {k: max(v[0] / max(v[1], 1) * 1e3 - ovh_h, 0.0) for k, v in st_h.items()}
+        m_h = ff.timed_mean_local
+        b_h = 9 * cam_h.width * cam_h.height + 60 * n_h + 88 * m_h + 44 * ff.timed_mean_new
+        timed = event_timer(torch, ff)
+        wp = np.eye(4, dtype=np.float32)
+        wp[:3, 3] = (0.01, -0.02, 0.005)
+        ff.map_warp(wp)
+        us_w2 = timed(lambda: ff.map_warp(wp), 50)
+        m_w2 = ff.map_size()
+        out["fullhd_2M"] = {
+            "workload": "BASELINE configs[4]: 1920x1080 depth stream against a live map of >= 2 M surfels, strictly serial (one stream)",
+            "frames_per_s": round(1.0 / dt_h, 1), "ms_per_frame": round(dt_h * 1e3, 3), "live_surfels": round(m_h),
+            "alg_bytes_per_frame": int(b_h), "e2e_hbm_frac": round(b_h / dt_h / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel_us": {k: round(v, 1) for k, v in per_h.items() if k in ("seed_points", "seed_fit", "fuse_surfels", "frame_tail",
+                                                                            "update_seeds_0", "assign_0")},
+            "frame_kernel_sum_us": round(sum(per_h.values()), 1),
+            "fuse_surfels": {"us": round(per_h["fuse_surfels"], 1), "alg_bytes": int(88 * m_h),
+                             "achieved_GBps": round(88 * m_h / per_h["fuse_surfels"] / 1e3, 1),
+                             "hbm_frac": round(88 * m_h / per_h["fuse_surfels"] / 1e3 / HBM_PEAK_GBS, 4),
+                             "timing": "HIP events around the kernel on the handle's stream (eager replay, 12 frames)"},
+            "map_warp": {"surfels": m_w2, "us": round(us_w2, 1), "alg_bytes": 88 * m_w2,
+                         "achieved_GBps": round(88 * m_w2 / us_w2 / 1e3, 1), "hbm_frac": round(88 * m_w2 / us_w2 / 1e3 / HBM_PEAK_GBS, 4),
+                         "timing": "HIP events around 50 back-to-back dsm_map_warp calls on the handle's stream; the 172 MB "
+                                   "array fits the 256 MB Infinity Cache, see map_warp_8M for the HBM-bound size"},
+        }
+        ff.close()
+        # the same kernel on a working set the Infinity Cache cannot hold: 8 M surfels = 352 MB read + 352 MB written
+        n_w = 8_000_000
         wm = np.zeros(n_w, api.SURFEL_DTYPE)
         wm["px"] = np.arange(n_w, dtype=np.float32) * 1e-3
         wm["nz"] = 1.0
         wm["update_times"] = 3
         ff = api.FusionFunctions.from_camera(synth.TINY, device=device, surfel_capacity=n_w + 64)
         ff.map_upload(wm)
-        wp = np.eye(4, dtype=np.float32)
-        wp[:3, 3] = (0.01, -0.02, 0.005)
-        for _ in range(5):
-            ff.map_warp(wp)
-        ff.synchronize()
-        t_w = time.perf_counter()
-        for _ in range(100):
-            ff.map_warp(wp)
-        ff.synchronize()
-        dt_w = (time.perf_counter() - t_w) / 100
-        out["map_warp_2M"] = {"us_per_call": round(dt_w * 1e6, 1), "achieved_GBps": round(n_w * 88 / dt_w / 1e9, 1),
-                              "hbm_frac": round(n_w * 88 / dt_w / 1e9 / HBM_PEAK_GBS, 4),
-                              "note": "dsm_map_warp incl. its per-call host sync; 176 MB working set sits in the 256 MB Infinity Cache "
-                                      "(kernel alone 26.8 us in profiles/r01_kernel_trace_warp_2M.md); 8 M surfels (704 MB): 5.1 TB/s"}
+        del wm
+        timed = event_timer(torch, ff)
+        ff.map_warp(wp)
+        us_w8 = timed(lambda: ff.map_warp(wp), 30)
+        out["map_warp_8M"] = {"surfels": n_w, "us": round(us_w8, 1), "alg_bytes": 88 * n_w, "achieved_GBps": round(88 * n_w / us_w8 / 1e3, 1),
+                              "hbm_frac": round(88 * n_w / us_w8 / 1e3 / HBM_PEAK_GBS, 4),
+                              "timing": "HIP events around 30 back-to-back dsm_map_warp calls (704 MB moved per call)"}
         ff.close()
 
-    if rank == 0 and world == 1 and not args.no_dropin:
+    if extras:
         # BASELINE configs[3]: live callback, 640x480 RGB-D constants, one frame at a time: host frame in
         # (H2D), resident map, one hipGraph replay, wait -- the latency the 30 Hz node would see per frame
-        cam_v = synth.VGA_RGBD
-        scene_v = synth.Scene(seed=5, scale=0.12, step=0.05, frames_per_period=30)
-        frames_v = [synth.render(cam_v, scene_v, i)[:2] for i in range(30)]
         ff = api.FusionFunctions.from_camera(cam_v, device=device, frame_slots=2, surfel_capacity=1 << 20)
         ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
         lat = []
@@ -366,14 +482,14 @@ def main():
                                         "note": "per frame: pageable host image+depth H2D, fuse (one graph replay), stream sync; RGB-D constant set"}
         ff.close()
 
-    if rank == 0 and world == 1 and not args.no_dropin:
+    if extras:
         # the whole node through its message callbacks (stamp matching, pose graph, active /
         # inactive sets in HBM, loop closure at the start of the second lap), host-inclusive: every frame is copied into
         # the node's page-locked pool and uploaded
         from densesurfelmapping_amd import surfel_map
         n_node = 3 * period
-        events = list(synth.node_messages(cam, scene, n_node, lap=period, frames={i: f for i, f in enumerate(rendered)}))
-        node = surfel_map.SurfelMap(cam, drift_free_poses=10, device=device, surfel_capacity=1 << 21)
+        events = list(synth.node_messages(cam, scenes[0], n_node, lap=period, frames={i: f for i, f in enumerate(rendered[0])}))
+        node = surfel_map.SurfelMap(cam, drift_free_poses=10, device=device, surfel_capacity=capacity)
         for ev in events[:60]:
             node.feed(ev)
         node.local_surfels()
@@ -389,7 +505,16 @@ def main():
         node.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cam, synth.Scene(seed=12345, frames_per_period=period), synth)
+        out["cpu_baseline"] = cpu_baseline(cam, scenes[0], rendered[0], period, lo_t, hi_t)
+        if k_avg is None:
+            k_avg = out["cpu_baseline"]["mean_new_surfels"]
+
+    if k_avg is None:
+        k_avg = 1400.0  # no measurement in this run (ranks > 0 / --no-roofline --no-cpu-baseline): a typical value
+        out["config"]["mean_new_surfels_assumed"] = k_avg
+    b_alg_frame = 9 * n_pix + 60 * n_seed + 88 * m_avg + 44 * k_avg
+    out["e2e_algorithmic_GBps"] = round(fps * b_alg_frame / 1e9, 2)
+    out["e2e_hbm_frac"] = round(fps * b_alg_frame / 1e9 / (HBM_PEAK_GBS * world), 5)
 
     if rank == 0:
         print(json.dumps(out))

@@ -75,7 +75,7 @@ class _Config(C.Structure):
 class _StageTimes(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("name", C.c_char_p * DSM_MAX_STAGES),
                 ("ms", C.c_double * DSM_MAX_STAGES), ("launches", C.c_int64 * DSM_MAX_STAGES),
-                ("frames", C.c_int64), ("event_overhead_ms", C.c_double)]
+                ("frames", C.c_int64), ("event_overhead_ms", C.c_double), ("sum_new", C.c_int64), ("sum_local", C.c_int64)]
 
 
 _vp = C.c_void_p
@@ -413,4 +413,6 @@ class FusionFunctions:
         self._check(self._lib.dsm_replay_timed(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm),
                                                C.byref(st)))
         self.event_overhead_ms = st.event_overhead_ms / max(st.frames, 1)
+        self.timed_mean_new = st.sum_new / max(st.frames, 1)      # K: surfels created per frame
+        self.timed_mean_local = st.sum_local / max(st.frames, 1)  # M: live surfels after a frame
         return {st.name[i].decode(): (st.ms[i], st.launches[i]) for i in range(st.n_stages)}, st.frames

@@ -48,7 +48,6 @@ struct dsm_handle {
     FrameParams *h_params = nullptr; // pinned staging ring
     int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
     FrameParams *d_params = nullptr;
-    float *d_warp = nullptr; // 16 floats
     uint8_t *d_stage_img = nullptr; // one tightly packed frame on its way into a pitched slot
     float *d_stage_depth = nullptr;
     // DSM_FLAG_UPLOAD_STREAM: frames go up on a stream of their own, so that the upload of the next frame overlaps the
@@ -453,7 +452,6 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     c.n_holes = scalars + 32; c.status = scalars + 48;
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
     c.params = h->d_params;
-    CREATE_TRY(dev_alloc(h, &h->d_warp, 16));
     h->ev_slot.assign((size_t)c.n_slots, nullptr);
     h->slot_used.assign((size_t)c.n_slots, 0);
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fence, hipEventDisableTiming));
@@ -669,12 +667,8 @@ int dsm_map_warp(dsm_handle *h, const float *warp16) {
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
     int rc = bind_device(h);
     if (rc) return rc;
-    // the matrix travels through the params ring's pinned staging: wait until the slot is free
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->frames_done = h->frames_submitted;
-    memcpy(h->h_scalars + 16, warp16, 64);
-    HIP_TRY(h, hipMemcpyAsync(h->d_warp, h->h_scalars + 16, 64, hipMemcpyHostToDevice, h->stream));
-    hipError_t e = launch_warp(h->hc.local, h->hc.n_local, 0, h->d_warp, nullptr, 0, h->map_upper, h->stream);
+    // the matrix travels in the kernel arguments: nothing to stage, nothing to wait for
+    hipError_t e = launch_warp(h->hc.local, h->hc.n_local, 0, nullptr, warp16, nullptr, 0, h->map_upper, h->stream);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "warp launch: %s", hipGetErrorString(e));
     return DSM_OK;
 }
@@ -695,7 +689,7 @@ int dsm_warp_grouped_device(dsm_handle *h, void *surfels_device, int32_t n_group
     hipError_t e = hipMemcpyAsync(d, mats16, b_m, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + b_m, offsets, b_o, hipMemcpyHostToDevice, h->stream);
     const int n = offsets[n_groups];
-    if (e == hipSuccess) e = launch_warp((dsm_surfel *)surfels_device, nullptr, n, (const float *)d, (const int32_t *)(d + b_m), n_groups, n, h->stream);
+    if (e == hipSuccess) e = launch_warp((dsm_surfel *)surfels_device, nullptr, n, (const float *)d, nullptr, (const int32_t *)(d + b_m), n_groups, n, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the host arrays may be reused
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "grouped warp: %s", hipGetErrorString(e));
     return DSM_OK;
@@ -852,7 +846,7 @@ int dsm_store_warp(dsm_handle *h, int32_t n_groups, const int32_t *offsets, cons
     if (e == hipSuccess) e = hipMemcpyAsync(d + b_m, offsets, b_o, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + b_m + b_o, changed, (size_t)n_groups, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess)
-        e = launch_warp(h->d_store, nullptr, h->store_n, (const float *)d, (const int32_t *)(d + b_m), n_groups, h->store_n, h->stream,
+        e = launch_warp(h->d_store, nullptr, h->store_n, (const float *)d, nullptr, (const int32_t *)(d + b_m), n_groups, h->store_n, h->stream,
                         (const uint8_t *)(d + b_m + b_o), h->d_cloud);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the host arrays may be reused
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "store warp: %s", hipGetErrorString(e));
@@ -1060,6 +1054,8 @@ int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32
         HIP_TRY(h, hipEventElapsedTime(&cal, h->ev[kNumStages], h->ev[kNumStages + 1]));
         out->event_overhead_ms += (double)cal;
         out->frames += 1;
+        out->sum_new += h->h_scalars[1];
+        out->sum_local += h->h_scalars[0];
     }
     return DSM_OK;
 }

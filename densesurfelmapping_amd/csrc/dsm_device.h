@@ -112,7 +112,11 @@ extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);
 
-hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
+struct WarpMat {
+    float m[16]; // column-major 4x4
+};
+// d_mats: per-group matrices in device memory, or nullptr: `single16` (host pointer, copied into the kernel arguments)
+hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats, const float *single16,
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st,
                        const uint8_t *d_group_on = nullptr, float4 *d_cloud = nullptr);
 hipError_t launch_mark(const DeviceCtx &ctx, int key, int n_upper, hipStream_t st);

@@ -73,7 +73,25 @@ __device__ __forceinline__ Blk16 load_blk(const float *l) {
     const float4 c = *reinterpret_cast<const float4 *>(l + 8), d = *reinterpret_cast<const float4 *>(l + 12);
     return Blk16{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w}};
 }
-__device__ __forceinline__ float ordered_sum(const float *l, int n) {
+// DSM_RELAXED_SUMS (experiment, never the shipped build): the order-sensitive sums of the plane fit (k_seed_points'
+// six fp32 sums, k_seed_fit's fourteen double sums) as four interleaved partial sums instead of one serial chain --
+// what the reference's summation order costs, measured (tools/relaxed_check.py).  The superpixel sweeps
+// keep their exact order in every build: labels are bit-exact by contract.
+#ifndef DSM_RELAXED_SUMS
+#define DSM_RELAXED_SUMS 0
+#endif
+__device__ __forceinline__ float ordered_sum(const float *l, int n, bool may_relax = false) {
+#if DSM_RELAXED_SUMS
+    if (may_relax) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int i = 0; i < n; i += kBlk) {
+            const Blk16 v = load_blk(l + i);
+#pragma unroll
+            for (int q = 0; q < kBlk; q += 4) { a0 += v.e[q]; a1 += v.e[q + 1]; a2 += v.e[q + 2]; a3 += v.e[q + 3]; }
+        }
+        return (a0 + a1) + (a2 + a3);
+    }
+#endif
     float a = 0.0f;
     for (int i = 0; i < n; i += kBlk) {
         const Blk16 v = load_blk(l + i);
@@ -619,7 +637,7 @@ __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx) {
         if (!((double)((float)m_in / (float)n) < 0.8)) { // FF.cpp:862
             // sequential fp32 sums, FF.cpp:852-857 and 111-116
             // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
-            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in);
+            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in, true);
             float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2);
             float mx = __shfl(part, 3), my = __shfl(part, 4), mz = __shfl(part, 5);
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
@@ -679,6 +697,17 @@ __device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const fl
     const float4 *x4 = reinterpret_cast<const float4 *>(xc), *y4 = reinterpret_cast<const float4 *>(yc);
     float4 xa = x4[0], xb = x4[1], ya = y4[0], yb = y4[1];
     double acc = 0.0;
+#if DSM_RELAXED_SUMS
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int b = 8; b <= m8; b += 8) {
+        const int nb = b < m8 ? b >> 2 : 0;
+        const float4 pxa = x4[nb], pxb = x4[nb + 1], pya = y4[nb], pyb = y4[nb + 1];
+        acc += (double)(xa.x * ya.x); a1 += (double)(xa.y * ya.y); a2 += (double)(xa.z * ya.z); a3 += (double)(xa.w * ya.w);
+        acc += (double)(xb.x * yb.x); a1 += (double)(xb.y * yb.y); a2 += (double)(xb.z * yb.z); a3 += (double)(xb.w * yb.w);
+        xa = pxa; xb = pxb; ya = pya; yb = pyb;
+    }
+    return 2.0 * ((acc + a1) + (a2 + a3));
+#endif
     for (int b = 8; b <= m8; b += 8) {
         const int nb = b < m8 ? b >> 2 : 0; // (the last round re-reads block 0 and drops it)
         const float4 pxa = x4[nb], pxb = x4[nb + 1], pya = y4[nb], pyb = y4[nb + 1];
@@ -1225,8 +1254,10 @@ __device__ __forceinline__ int warp_group_of(const int32_t *__restrict__ group_o
     }
     return lo;
 }
+// One matrix for all travels in the kernel-argument segment (`single`, used when mats == nullptr): no staging buffer,
+// nothing for the host to wait for between two calls.
 __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, const int32_t *__restrict__ n_ptr,
-                                              int32_t n_fixed, const float *__restrict__ mats,
+                                              int32_t n_fixed, const float *__restrict__ mats, const WarpMat single,
                                               const int32_t *__restrict__ group_offsets, int32_t n_groups,
                                               const uint8_t *__restrict__ group_on, float4 *__restrict__ cloud) {
     __shared__ __attribute__((aligned(16))) float s_rec[256 * 11];
@@ -1254,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
         }
         __syncthreads();
         if (tid < cnt) {
-            const float *m = mats;
+            const float *m = mats ? mats : single.m;
             bool on = true;
             int g = 0;
             if (group_offsets) {
@@ -1324,13 +1355,15 @@ __global__ void k_append(const DeviceCtx ctx, int n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) c->n_local[0] = c->n_local[0] + n;
 }
 
-hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats,
+hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats, const float *single16,
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st, const uint8_t *d_group_on,
                        float4 *d_cloud) {
     int blocks = (n_upper + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, d_offsets, n_groups,
+    WarpMat one;
+    for (int i = 0; i < 16; i++) one.m[i] = single16 ? single16[i] : 0.0f;
+    hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, one, d_offsets, n_groups,
                        d_group_on, d_cloud);
     return hipGetLastError();
 }

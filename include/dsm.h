@@ -231,6 +231,8 @@ typedef struct dsm_stage_times {
     int64_t launches[DSM_MAX_STAGES];
     int64_t frames;
     double event_overhead_ms;       /* accumulated length of one empty event-to-event interval per frame */
+    int64_t sum_new;                /* surfels created, summed over the frames (K of SURVEY.md's B_alg) */
+    int64_t sum_local;              /* live map size after each frame, summed over the frames (M) */
 } dsm_stage_times;
 /* run the resident fuse for n frames eagerly with an event pair around every kernel and
  * accumulate per-stage durations */

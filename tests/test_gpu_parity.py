@@ -696,7 +696,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--streams", "2"],
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--streams", "2", "--frames-per-step", "4"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
