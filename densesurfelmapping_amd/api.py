@@ -240,6 +240,19 @@ class FusionFunctions:
             _ptr(pose_cm), _ptr(buf), C.byref(n_local), cap, C.byref(n_new)))
         return buf[: n_local.value].copy(), n_new.value
 
+    def fuse_map_inplace(self, reference_frame_index, image, depth, pose, buf, n_local):
+        """dsm_fuse_map on the caller's own array, as the C++ caller uses it (`buf` = std::vector storage with
+        capacity len(buf), the first n_local records live): no copies on the Python side.  Returns (n_local, n_new)."""
+        image, depth = self._frame_args(image, depth)
+        pose_cm = pose_to_colmajor(pose)
+        assert buf.dtype == SURFEL_DTYPE and buf.flags.c_contiguous
+        n = C.c_int32(n_local)
+        n_new = C.c_int32(0)
+        self._check(self._lib.dsm_fuse_map(
+            self._h, reference_frame_index, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0],
+            _ptr(pose_cm), _ptr(buf), C.byref(n), len(buf), C.byref(n_new)))
+        return n.value, n_new.value
+
     # ---- resident path -------------------------------------------------------------------
     def map_upload(self, surfels):
         a = np.ascontiguousarray(surfels, SURFEL_DTYPE)

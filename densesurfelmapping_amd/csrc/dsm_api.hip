@@ -10,7 +10,12 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dsm_device.h"
@@ -26,6 +31,76 @@ constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 
 } // namespace
 
+// A few host threads for the drop-in calls' bulk copies (frame rows into page-locked staging, the caller's surfel
+// array against / into / out of its page-locked shadow): one core moves ~15 GB/s, the copies of a 100 k-surfel map
+// would otherwise be most of a drop-in frame.
+class HostPool {
+  public:
+    explicit HostPool(int n_workers) {
+        for (int i = 0; i < n_workers; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : workers_) t.join();
+    }
+    // fn(i) for i in [0, n): the caller takes part
+    void run(int n, const std::function<void(int)> &fn) {
+        if (n <= 1 || workers_.empty()) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            next_.store(0);
+            n_ = n;
+            done_ = 0;
+            gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return done_ == n_; });
+        fn_ = nullptr;
+    }
+    int width() const { return (int)workers_.size() + 1; }
+
+  private:
+    void work() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) return;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (++done_ == n_) done_cv_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, done_ = 0;
+    unsigned gen_ = 0;
+    bool stop_ = false;
+};
+
 struct dsm_handle {
     dsm_config cfg;
     int device = 0;
@@ -38,6 +113,7 @@ struct dsm_handle {
         hipStream_t stream = nullptr;
         DeviceCtx ctx;
         hipGraphExec_t g_sp = nullptr, g_map[2] = {nullptr, nullptr}, g_all[2] = {nullptr, nullptr};
+        hipGraphExec_t g_sp_main = nullptr; // superpixel stages on the map stream (drop-in calls)
         hipEvent_t ev_sp = nullptr, ev_map = nullptr;
     } pipe[8];
     int n_pipe = 1;
@@ -73,6 +149,12 @@ struct dsm_handle {
     void *d_store_tmp = nullptr;
     size_t store_tmp_bytes = 0;
     int store_cap = 0, store_n = 0;
+    // drop-in calls (dsm_fuse_map / dsm_fuse_initialize_map): page-locked staging owned by the handle
+    uint8_t *pin_frame = nullptr; // one frame, image then depth, tightly packed rows
+    dsm_surfel *pin_map = nullptr; // shadow of the caller's array: what the last drop-in call returned == the device map
+    size_t pin_map_cap = 0;
+    int shadow_n = -1;             // -1: the device map is not known to equal the shadow (resident calls in between)
+    HostPool *pool = nullptr;
     std::string err;
 };
 
@@ -197,6 +279,7 @@ int capture(dsm_handle *h, hipStream_t st, const DeviceCtx &ctx, bool with_compa
 // enqueue the kernels of one frame whose params were staged by stage_params: superpixel stages on the
 // frame's pipeline stream, fuse + tail on the map stream
 int submit_frame(dsm_handle *h, bool with_compaction) {
+    h->shadow_n = -1;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
     const bool eager = (h->cfg.flags & DSM_FLAG_NO_GRAPH) != 0;
@@ -249,6 +332,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
 
 // run some or all stages of the next frame serially on the map stream (timed replays, state-level taps)
 int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, int hi) {
+    h->shadow_n = -1;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
     if (h->n_pipe > 1 && (h->params_pending & 0x100u)) {
@@ -267,6 +351,114 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
             if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
         }
     }
+    return DSM_OK;
+}
+
+// ---- drop-in calls: everything on the map stream, in two parts, so that the host can look at the caller's surfel
+// array while the superpixel stages (which need the frame only) already run
+int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
+    const int p = (int)(h->frames_submitted % h->n_pipe);
+    dsm_handle::Pipe &pp = h->pipe[p];
+    if (h->n_pipe > 1 && (h->params_pending & 0x100u)) {
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
+        h->params_pending &= ~0x100u;
+    }
+    const int lo = map_part ? kLastSuperpixelStage + 1 : 0, hi = map_part ? kNumStages - 1 : kLastSuperpixelStage;
+    if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
+        hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, nullptr, lo, hi);
+        if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    } else {
+        hipGraphExec_t *g = map_part ? &pp.g_map[with_compaction ? 1 : 0] : &pp.g_sp_main;
+        int rc = capture(h, h->stream, pp.ctx, with_compaction, lo, hi, g);
+        if (rc) return rc;
+        HIP_TRY(h, hipGraphLaunch(*g, h->stream));
+    }
+    if (map_part) {
+        if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+        h->hc = pp.ctx;
+        h->frames_submitted++;
+        if (with_compaction) {
+            h->map_upper += h->hc.n_seed;
+            if (h->map_upper > h->hc.cap) h->map_upper = h->hc.cap;
+        }
+    }
+    return DSM_OK;
+}
+
+constexpr size_t kParChunk = 1 << 20; // bytes per task of the parallel copies
+
+void par_copy(dsm_handle *h, void *dst, const void *src, size_t bytes) {
+    const int n = (int)((bytes + kParChunk - 1) / kParChunk);
+    h->pool->run(n, [&](int i) {
+        const size_t o = (size_t)i * kParChunk, len = bytes - o < kParChunk ? bytes - o : kParChunk;
+        memcpy((char *)dst + o, (const char *)src + o, len);
+    });
+}
+
+bool par_equal(dsm_handle *h, const void *a, const void *b, size_t bytes) {
+    const int n = (int)((bytes + kParChunk - 1) / kParChunk);
+    std::atomic<int> differ{0};
+    h->pool->run(n, [&](int i) {
+        const size_t o = (size_t)i * kParChunk, len = bytes - o < kParChunk ? bytes - o : kParChunk;
+        if (!differ.load(std::memory_order_relaxed) && memcmp((const char *)a + o, (const char *)b + o, len) != 0) differ.store(1);
+    });
+    return differ.load() == 0;
+}
+
+// page-locked staging of the drop-in calls, grown on demand
+int dropin_reserve(dsm_handle *h, size_t map_records) {
+    if (!h->pool) h->pool = new HostPool(3);
+    if (!h->pin_frame) HIP_TRY(h, hipHostMalloc((void **)&h->pin_frame, (size_t)h->hc.w * h->hc.h * 5, hipHostMallocDefault));
+    if (map_records > h->pin_map_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        size_t cap = h->pin_map_cap ? h->pin_map_cap : (size_t)1 << 16;
+        while (cap < map_records) cap *= 2;
+        dsm_surfel *n = nullptr;
+        HIP_TRY(h, hipHostMalloc((void **)&n, cap * sizeof(dsm_surfel), hipHostMallocDefault));
+        if (h->pin_map) (void)hipHostFree(h->pin_map);
+        h->pin_map = n;
+        h->pin_map_cap = cap;
+        h->shadow_n = -1;
+    }
+    return DSM_OK;
+}
+
+// frame into slot 0 without a host wait: rows -> page-locked staging -> device staging -> pitched slot (repack kernel)
+int dropin_frame(dsm_handle *h, const uint8_t *image, size_t img_step, const float *depth, size_t depth_step) {
+    if (!image || !depth) return fail(h, DSM_E_INVALID, "null image/depth");
+    const int w = h->hc.w, hh = h->hc.h;
+    if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
+    const size_t n = (size_t)w * hh;
+    uint8_t *pi = h->pin_frame;
+    uint8_t *pd = h->pin_frame + n;
+    h->pool->run(hh, [&](int y) {
+        memcpy(pi + (size_t)y * w, image + (size_t)y * img_step, (size_t)w);
+        memcpy(pd + (size_t)y * w * 4, (const uint8_t *)depth + (size_t)y * depth_step, (size_t)w * 4);
+    });
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage_img, pi, n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage_depth, pd, n * 4, hipMemcpyHostToDevice, h->stream));
+    const hipError_t e = launch_repack((uint8_t *)h->hc.img_base, (float *)h->hc.depth_base, h->hc.pitch, h->d_stage_img, h->d_stage_depth, w, hh,
+                                       h->stream);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "frame repack: %s", hipGetErrorString(e));
+    return DSM_OK;
+}
+
+// the caller's surfel array becomes the device map -- unless it still is what the previous drop-in call handed back
+// (SurfelMap::fuse_map passes the same vector every frame and edits it only when keyframes enter or leave the window)
+int dropin_map_in(dsm_handle *h, const dsm_surfel *local, int n) {
+    if (n < 0 || (n > 0 && !local)) return fail(h, DSM_E_INVALID, "bad surfel array");
+    if (n > h->hc.cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the handle's capacity %d", n, h->hc.cap);
+    const size_t bytes = (size_t)n * sizeof(dsm_surfel);
+    if (h->shadow_n == n && h->map_valid && par_equal(h, local, h->pin_map, bytes)) return DSM_OK;
+    h->shadow_n = -1;
+    if (n) {
+        par_copy(h, h->pin_map, local, bytes);
+        HIP_TRY(h, hipMemcpyAsync(h->hc.local, h->pin_map, bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    h->h_scalars[3] = n;
+    HIP_TRY(h, hipMemcpyAsync(h->hc.n_local, &h->h_scalars[3], 4, hipMemcpyHostToDevice, h->stream));
+    h->map_upper = n;
+    h->map_valid = true;
     return DSM_OK;
 }
 
@@ -338,6 +530,7 @@ int upload_frame(dsm_handle *h, int slot, const void *image, size_t img_step, co
 }
 
 int set_map(dsm_handle *h, const dsm_surfel *src, int n) {
+    h->shadow_n = -1;
     if (n < 0 || (n > 0 && !src)) return fail(h, DSM_E_INVALID, "bad surfel array");
     if (n > h->hc.cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the handle's capacity %d", n, h->hc.cap);
     if (n) HIP_TRY(h, hipMemcpyAsync(h->hc.local, src, (size_t)n * sizeof(dsm_surfel), hipMemcpyHostToDevice, h->stream));
@@ -522,6 +715,7 @@ void dsm_destroy(dsm_handle *h) {
         dsm_handle::Pipe &pp = h->pipe[p];
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
         if (pp.g_sp) (void)hipGraphExecDestroy(pp.g_sp);
+        if (pp.g_sp_main) (void)hipGraphExecDestroy(pp.g_sp_main);
         for (int i = 0; i < 2; i++) {
             if (pp.g_map[i]) (void)hipGraphExecDestroy(pp.g_map[i]);
             if (pp.g_all[i]) (void)hipGraphExecDestroy(pp.g_all[i]);
@@ -544,6 +738,9 @@ void dsm_destroy(dsm_handle *h) {
     if (h->d_store_tmp) (void)hipFree(h->d_store_tmp);
     if (h->h_params) (void)hipHostFree(h->h_params);
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
+    if (h->pin_frame) (void)hipHostFree(h->pin_frame);
+    if (h->pin_map) (void)hipHostFree(h->pin_map);
+    delete h->pool;
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -575,16 +772,24 @@ int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint
     if (!pose16 || !n_new || (new_cap > 0 && !new_out) || new_cap < 0) return fail(h, DSM_E_INVALID, "null/negative argument");
     int rc = bind_device(h);
     if (rc) return rc;
-    if ((rc = upload_frame(h, 0, image, img_step, depth, depth_step, hipMemcpyHostToDevice))) return rc;
-    if ((rc = set_map(h, local, n_local))) return rc;
+    const int S = h->hc.n_seed;
+    if ((rc = dropin_reserve(h, (size_t)(n_local > 0 ? n_local : 0) + (size_t)S))) return rc;
+    if ((rc = dropin_frame(h, image, img_step, depth, depth_step))) return rc;
     if ((rc = stage_params(h, 0, reference_frame_index, pose16))) return rc;
-    if ((rc = submit_frame(h, false))) return rc;
-    if ((rc = sync_and_fetch_counts(h))) return rc;
+    if ((rc = submit_part(h, false, false))) return rc;            // superpixels run while the host compares / copies the map
+    if ((rc = dropin_map_in(h, local, n_local))) return rc;
+    if ((rc = submit_part(h, false, true))) return rc;
+    // results into the shadow: the updated map, then (behind it) the new surfels
+    const size_t b_map = (size_t)n_local * sizeof(dsm_surfel);
+    if (n_local) HIP_TRY(h, hipMemcpyAsync(h->pin_map, h->hc.local, b_map, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_map + n_local, h->hc.fresh, (size_t)S * sizeof(dsm_surfel), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = sync_and_fetch_counts(h))) { h->shadow_n = -1; return rc; }
     const int k = h->h_scalars[1];
     *n_new = k;
-    if (n_local) HIP_TRY(h, hipMemcpy(local, h->hc.local, (size_t)n_local * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    if (n_local) par_copy(h, local, h->pin_map, b_map);
+    h->shadow_n = n_local; // no compaction: the device map keeps its size
     if (k > new_cap) return fail(h, DSM_E_CAPACITY, "%d new surfels exceed new_cap %d", k, new_cap);
-    if (k) HIP_TRY(h, hipMemcpy(new_out, h->hc.fresh, (size_t)k * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    if (k) memcpy(new_out, h->pin_map + n_local, (size_t)k * sizeof(dsm_surfel));
     return DSM_OK;
 }
 
@@ -596,16 +801,26 @@ int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image,
         return fail(h, DSM_E_INVALID, "null/negative argument");
     int rc = bind_device(h);
     if (rc) return rc;
-    if ((rc = upload_frame(h, 0, image, img_step, depth, depth_step, hipMemcpyHostToDevice))) return rc;
-    if ((rc = set_map(h, local, *n_local))) return rc;
+    const int n_in = *n_local, S = h->hc.n_seed;
+    // after the frame the map holds at most n_in + S surfels (every seed creates at most one)
+    size_t n_back = (size_t)n_in + (size_t)S;
+    if (n_back > (size_t)h->hc.cap) n_back = (size_t)h->hc.cap;
+    if ((rc = dropin_reserve(h, n_back > (size_t)n_in ? n_back : (size_t)n_in))) return rc;
+    if ((rc = dropin_frame(h, image, img_step, depth, depth_step))) return rc;
     if ((rc = stage_params(h, 0, reference_frame_index, pose16))) return rc;
-    if ((rc = submit_frame(h, true))) return rc;
+    if ((rc = submit_part(h, true, false))) return rc;             // superpixels run while the host compares / copies the map
+    if ((rc = dropin_map_in(h, local, n_in))) return rc;
+    if ((rc = submit_part(h, true, true))) return rc;
+    // the whole possible extent comes back in one copy enqueued behind the frame: no wait for the new size first
+    if (n_back) HIP_TRY(h, hipMemcpyAsync(h->pin_map, h->hc.local, n_back * sizeof(dsm_surfel), hipMemcpyDeviceToHost, h->stream));
+    h->shadow_n = -1;
     if ((rc = sync_and_fetch_counts(h))) return rc;
     const int m = h->h_scalars[0];
     *n_new = h->h_scalars[1];
     if (m > cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap);
-    if (m) HIP_TRY(h, hipMemcpy(local, h->hc.local, (size_t)m * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+    if (m) par_copy(h, local, h->pin_map, (size_t)m * sizeof(dsm_surfel));
     *n_local = m;
+    h->shadow_n = m;
     return DSM_OK;
 }
 
@@ -663,6 +878,7 @@ int dsm_map_copy_to_device(dsm_handle *h, void *dst_device, int32_t cap, int32_t
 
 int dsm_map_warp(dsm_handle *h, const float *warp16) {
     if (!h) return DSM_E_INVALID;
+    h->shadow_n = -1;
     if (!warp16) return fail(h, DSM_E_INVALID, "null matrix");
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
     int rc = bind_device(h);
@@ -697,6 +913,7 @@ int dsm_warp_grouped_device(dsm_handle *h, void *surfels_device, int32_t n_group
 
 int dsm_map_extract(dsm_handle *h, int32_t key, dsm_surfel *out, int32_t cap, int32_t *n) {
     if (!h || !n || cap < 0 || (cap > 0 && !out)) return DSM_E_INVALID;
+    h->shadow_n = -1;
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
     int rc = bind_device(h);
     if (rc) return rc;
@@ -722,6 +939,7 @@ int dsm_map_extract(dsm_handle *h, int32_t key, dsm_surfel *out, int32_t cap, in
 
 int dsm_map_append(dsm_handle *h, const dsm_surfel *surfels, int32_t n) {
     if (!h || n < 0 || (n > 0 && !surfels)) return DSM_E_INVALID;
+    h->shadow_n = -1;
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
     int rc = bind_device(h);
     if (rc) return rc;
@@ -772,6 +990,7 @@ int dsm_store_size(dsm_handle *h, int32_t *n) {
 
 int dsm_store_deactivate(dsm_handle *h, int32_t key, int32_t *begin, int32_t *n) {
     if (!h || !begin || !n) return DSM_E_INVALID;
+    h->shadow_n = -1;
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
     int rc = bind_device(h);
     if (rc) return rc;
@@ -795,6 +1014,7 @@ int dsm_store_deactivate(dsm_handle *h, int32_t key, int32_t *begin, int32_t *n)
 
 int dsm_store_activate(dsm_handle *h, int32_t begin, int32_t n) {
     if (!h) return DSM_E_INVALID;
+    h->shadow_n = -1;
     if (begin < 0 || n < 0 || begin + n > h->store_n) return fail(h, DSM_E_INVALID, "store range [%d,+%d) outside [0,%d)", begin, n, h->store_n);
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map");
     int rc = bind_device(h);

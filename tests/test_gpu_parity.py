@@ -70,6 +70,48 @@ def test_dropin_fuse_initialize_map(mods):
         lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
 
 
+def test_dropin_shadow_detects_caller_edits(mods):
+    """dsm_fuse_map keeps a page-locked shadow of what it returned and skips the map upload when the caller hands the
+    same bytes back.  Everything that can make the device map differ from the caller's array must be noticed: edits of
+    single records, a shorter or longer array, resident calls in between, fuse_initialize_map in between."""
+    api, synth, ob = mods
+    cam, scene = synth.VGA_DRIVE, synth.Scene(seed=41)
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=2, surfel_capacity=1 << 18)
+    orc = ob.PortOracle(cam)
+    buf = np.zeros(1 << 17, api.SURFEL_DTYPE)
+    n = 0
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    rng = np.random.default_rng(2)
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, 16):
+        if t == 3:      # one record edited in place (same length)
+            buf["pz"][n // 2] += 0.25
+            lo["pz"][n // 2] += 0.25
+        if t == 5:      # records deleted by the caller (move_add_surfels marks update_times = 0, SM.cpp:1494)
+            kill = rng.random(n) < 0.2
+            buf["update_times"][:n][kill] = 0
+            lo["update_times"][kill] = 0
+        if t == 7:      # shorter array
+            n -= 100
+            lo = lo[:n].copy()
+        if t == 9:      # longer array: surfels of a re-activated keyframe appended (SM.cpp:1583-1590)
+            extra = lo[:50].copy()
+            extra["px"] += 0.5
+            buf[n:n + 50] = extra.astype(api.SURFEL_DTYPE)
+            lo = np.concatenate([lo, extra])
+            n += 50
+        if t == 11:     # a resident call replaces the device map behind the shadow's back
+            ff.map_upload(np.zeros(10, api.SURFEL_DTYPE))
+        if t == 13:     # fuse_initialize_map (no compaction) in between: the shadow follows
+            g_local, g_new = ff.fuse_initialize_map(ref, img, dep, pose, buf[:n])
+            o_local, o_new = orc.fuse_initialize_map(ref, img, dep, pose, lo)
+            assert fields_equal(g_local, o_local.astype(api.SURFEL_DTYPE)) == [] and fields_equal(g_new, o_new.astype(api.SURFEL_DTYPE)) == []
+        n, k = ff.fuse_map_inplace(ref, img, dep, pose, buf, n)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert k == ko and n == len(lo), f"frame {t}"
+        assert fields_equal(buf[:n], lo.astype(api.SURFEL_DTYPE)) == [], f"frame {t}"
+    ff.close()
+
+
 def test_resident_replay_kitti(mods):
     """BASELINE config 2 shape: 1226x370, map and frames resident in HBM, one graph replay per frame."""
     api, synth, ob = mods
