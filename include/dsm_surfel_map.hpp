@@ -177,13 +177,80 @@ class SurfelMap {
         return o;
     }
     int check(int rc) {
-#ifndef DSM_NO_EXCEPTIONS
+#if !defined(DSM_NO_EXCEPTIONS) && !defined(DSM_WITH_ROS)
         if (rc != DSM_OK) throw std::runtime_error(std::string("dsm::SurfelMap: ") + dsm_surfel_map_last_error(m_));
 #endif
-        return rc;
+        return rc; // (with DSM_WITH_ROS the callbacks report and carry on, as the reference's void callbacks do)
     }
     dsm_surfel_map *m_ = nullptr;
 };
 
 } // namespace dsm
+
+#ifdef DSM_WITH_ROS
+// ---- the reference's class, signature for signature (surfel_map.h:48-62), for roscpp builds ------------------------
+// `SurfelMap surfel_map(nh);` and the subscriber wiring of surfel_fusion/src/ros_node.cpp:22-32
+//     nh.subscribe("image", 5000, &SurfelMap::image_input, &surfel_map);
+//     sync.registerCallback(boost::bind(&SurfelMap::orb_results_input, &surfel_map, _1, _2, _3));
+// bind to these members unchanged: they are plain (non-template, non-overloaded) member functions returning void.
+// include/ros_compat/surfel_map.h puts this class behind the reference's own header name, so that ros_node.cpp
+// compiles without an edit when that directory precedes the reference's src/ on the include path.
+// Errors: the reference returns void and prints (surfel_map.cpp:31-32); so does this class (stderr), except that a
+// constructor that cannot reach a gfx950 device throws std::runtime_error -- there is no CPU path to fall back to.
+#include <cstdio>
+
+#include <nav_msgs/Odometry.h>
+#include <nav_msgs/Path.h>
+#include <ros/ros.h>
+#include <sensor_msgs/Image.h>
+#include <sensor_msgs/PointCloud.h>
+#include <std_msgs/String.h>
+
+class SurfelMap {
+  public:
+    SurfelMap(ros::NodeHandle &_nh) : nh(_nh), impl_(params_from(_nh)) {}
+    ~SurfelMap() {}
+
+    void image_input(const sensor_msgs::ImageConstPtr &image_input) { report(impl_.image_input(image_input), "image_input"); }
+    void depth_input(const sensor_msgs::ImageConstPtr &image_input) { report(impl_.depth_input(image_input), "depth_input"); }
+    void orb_results_input(const sensor_msgs::PointCloudConstPtr &loop_stamp_input, const nav_msgs::PathConstPtr &loop_path_input,
+                           const nav_msgs::OdometryConstPtr &this_pose_input) {
+        report(impl_.orb_results_input(loop_stamp_input, loop_path_input, this_pose_input), "orb_results_input");
+    }
+    void save_cloud(std::string save_path_name) { report(impl_.save_cloud(save_path_name), "save_cloud"); }
+    void save_mesh(std::string save_path_name) { report(impl_.save_mesh(save_path_name), "save_mesh"); }
+    void save_map(const std_msgs::StringConstPtr &save_map_input) { // surfel_map.cpp:75-81
+        std::string save_name = save_map_input->data;
+        printf("save mesh modelt to %s.\n", save_name.c_str());
+        save_mesh(save_name);
+        printf("save done!\n");
+    }
+
+    dsm::SurfelMap &engine_node() { return impl_; }
+
+  private:
+    // the nine parameters of surfel_map.cpp:14-29
+    static dsm::SurfelMap::Params params_from(ros::NodeHandle &nh) {
+        dsm::SurfelMap::Params p;
+        bool get_all = true;
+        get_all &= nh.getParam("cam_width", p.cam_width);
+        get_all &= nh.getParam("cam_height", p.cam_height);
+        get_all &= nh.getParam("cam_fx", p.cam_fx);
+        get_all &= nh.getParam("cam_cx", p.cam_cx);
+        get_all &= nh.getParam("cam_fy", p.cam_fy);
+        get_all &= nh.getParam("cam_cy", p.cam_cy);
+        get_all &= nh.getParam("fuse_far_distence", p.fuse_far_distence);
+        get_all &= nh.getParam("fuse_near_distence", p.fuse_near_distence);
+        get_all &= nh.getParam("drift_free_poses", p.drift_free_poses);
+        if (!get_all) printf("ERROR! Do not have enough parameters!");
+        else printf("fuse the distence between %4f m and %4f m.\n", p.fuse_near_distence, p.fuse_far_distence);
+        return p;
+    }
+    void report(int rc, const char *what) {
+        if (rc != DSM_OK) fprintf(stderr, "SurfelMap::%s: %s\n", what, dsm_surfel_map_last_error(impl_.handle()));
+    }
+    ros::NodeHandle &nh;
+    dsm::SurfelMap impl_;
+};
+#endif // DSM_WITH_ROS
 #endif

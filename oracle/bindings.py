@@ -197,9 +197,11 @@ class RefSurfelMap:
     in place, oracle/ref_map_driver.cpp) behind the same message-level interface as
     densesurfelmapping_amd.surfel_map.SurfelMap."""
 
-    def __init__(self, cam, drift_free_poses=10, kind=None):
+    def __init__(self, cam, drift_free_poses=10, kind=None, lib_path=None):
         # kind "map_threads": real std::threads, for timing only (the reference's warp_surfels races, SM.cpp:791-824)
-        lib = C.CDLL(ref_lib_path(kind or ("map_rgbd" if cam.rgbd else "map")))
+        # lib_path: another build of the same driver (tests/_build/libdsm_ref_map_on_product.so: the reference's
+        # surfel_map.cpp on top of the product's engine facade)
+        lib = C.CDLL(lib_path or ref_lib_path(kind or ("map_rgbd" if cam.rgbd else "map")))
         lib.refmap_create.restype = _vp
         lib.refmap_create.argtypes = [C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_int]
         lib.refmap_destroy.argtypes = [_vp]

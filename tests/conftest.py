@@ -88,3 +88,50 @@ def node_hostemu_lib(oracle_built):
               "-I" + os.path.join(ROOT, "include"), deps[0], "-o", out, "-L" + oracle_built, "-l:liboracle_port.so",
               "-Wl,-rpath," + oracle_built])
     return out
+
+
+REF_SRC = "/root/reference/surfel_fusion/src"
+PKG = os.path.join(ROOT, "densesurfelmapping_amd")
+_LINK = ["-L" + PKG, "-l:libdsm_hip.so", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def _prebuilt_or_skip(out):
+    if not os.path.exists(out):
+        pytest.skip("reference sources not present and no prebuilt " + os.path.basename(out))
+    return out
+
+
+@pytest.fixture(scope="session")
+def ros_node_on_product():
+    """The reference's own surfel_fusion/src/ros_node.cpp, compiled IN PLACE and UNCHANGED, with include/ros_compat in
+    front of it: `SurfelMap surfel_map(nh)` and its subscriber bindings are the product's node class.  ROS itself is
+    shimmed (oracle/shims + tests/ros_shims: a message pump fed from a recorded log).  Built where the reference
+    exists; the binary travels to the GPU box."""
+    out = os.path.join(ROOT, "tests", "_build", "ros_node_on_product")
+    if not os.path.isdir(REF_SRC):
+        return _prebuilt_or_skip(out)
+    from densesurfelmapping_amd import build
+    build.build_library()
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    _run(["g++", "-std=c++11", "-O1", "-w", "-I" + os.path.join(ROOT, "include", "ros_compat"), "-I" + os.path.join(ROOT, "tests", "ros_shims"),
+          "-I" + os.path.join(ROOT, "oracle", "shims"), os.path.join(REF_SRC, "ros_node.cpp"),
+          os.path.join(ROOT, "tests", "ros_shims", "ros_shim_bus.cpp"), "-o", out] + _LINK)
+    return out
+
+
+@pytest.fixture(scope="session")
+def ref_map_on_product():
+    """INTEGRATION.md §2 as a build: the reference's surfel_map.{h,cpp} compiled in place and unchanged with
+    include/engine_compat in front (its `#include <fusion_functions.h>` resolves to the product's facade), linked against
+    libdsm_hip.so -- the reference's node class running on the HIP engine through the drop-in call."""
+    out = os.path.join(ROOT, "tests", "_build", "libdsm_ref_map_on_product.so")
+    if not os.path.isdir(REF_SRC):
+        return _prebuilt_or_skip(out)
+    from densesurfelmapping_amd import build
+    build.build_library()
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    _run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++11", "-O3", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
+          "-ftrivial-auto-var-init=zero", "-fno-access-control", "-w", "-DDSM_ORACLE_QUIET", "-DDSM_ORACLE_DEFERRED_THREADS",
+          "-I" + os.path.join(ROOT, "include", "engine_compat"), "-I" + os.path.join(ROOT, "oracle", "shims"), "-I" + REF_SRC,
+          "-o", out, os.path.join(ROOT, "oracle", "ref_map_driver.cpp")] + _LINK)
+    return out

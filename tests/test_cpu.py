@@ -567,6 +567,31 @@ def test_node_survives_a_lost_frame_and_bounds_its_buffers(node_hostemu_lib, syn
     node.close()
 
 
+# ------------------------------------------------------------------ the reference's own sources on top of the product
+def test_reference_ros_node_compiles_unchanged_against_the_product(ros_node_on_product, synth, tmp_path):
+    """surfel_fusion/src/ros_node.cpp (main(), the nh.subscribe / message_filters wiring, the save calls) builds against
+    include/ros_compat/surfel_map.h without an edit; without a GPU its `SurfelMap surfel_map(nh)` refuses to start."""
+    import node_state
+    case = node_state.SCENARIOS[0]
+    log = str(tmp_path / "events.bin")
+    _write_node_events(log, synth.NODE_CAM, dict(case, frames=4), synth)
+    env = dict(os.environ, DSM_ROS_SHIM_LOG=log, DSM_ROS_SHIM_SAVE_NAME=str(tmp_path / "out"))
+    r = subprocess.run([ros_node_on_product], env=env, capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr[-2000:]
+    else:
+        assert r.returncode != 0 and "dsm::SurfelMap" in r.stderr, r.stderr[-2000:]
+
+
+def test_reference_surfel_map_compiles_unchanged_on_the_engine_facade(ref_map_on_product):
+    """surfel_map.cpp + surfel_map.h of the reference, not a line changed, with FusionFunctions =
+    the HIP engine's facade.  (Run on the GPU by test_gpu_parity.py::test_reference_node_on_the_hip_engine.)"""
+    out = subprocess.run(["nm", "-D", "--undefined-only", ref_map_on_product], capture_output=True, text=True, check=True).stdout
+    assert " dsm_fuse_initialize_map" in out and " dsm_create" in out  # the reference's node calls into the product's C ABI
+    assert "fuse_surfels_kernel" not in subprocess.run(["nm", "-D", "-C", ref_map_on_product], capture_output=True, text=True).stdout
+
+
 # ------------------------------------------------------------------ parity at scale (vectors: tests/golden/make_golden_long.py)
 def _map_sha(a, dtype):
     from node_state import _canon

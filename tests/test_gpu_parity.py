@@ -696,6 +696,38 @@ def test_node_matches_reference_node(mods):
         test_cpu._check_node_run(case, gold, lambda cam, d: surfel_map.SurfelMap(cam, drift_free_poses=d))
 
 
+def test_reference_ros_node_on_the_product(mods, ros_node_on_product, tmp_path):
+    """The reference's ros_node.cpp, compiled unchanged against include/ros_compat (exact ROS callback signatures, the
+    SurfelMap(ros::NodeHandle&) constructor reading the nine parameters), pumping a recorded message stream through its
+    own subscriber wiring: the PCD and PLY its main() saves at exit are the reference node's, byte for byte."""
+    import subprocess
+    import node_state
+    import test_cpu
+    api, synth, ob = mods
+    case, gold = test_cpu._node_cases()[0]
+    log = str(tmp_path / "events.bin")
+    test_cpu._write_node_events(log, synth.NODE_CAM, case, synth)
+    env = dict(os.environ, DSM_ROS_SHIM_LOG=log, DSM_ROS_SHIM_SAVE_NAME=str(tmp_path / "map"))
+    r = subprocess.run([ros_node_on_product], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    for kind, path in (("pcd", str(tmp_path / "map.PCD")), ("ply", str(tmp_path / "map_mesh.PLY"))):
+        got = node_state.file_digest(path)
+        assert got["head"] == gold["files"][kind]["head"] and got["sha256"] == gold["files"][kind]["sha256"], kind
+
+
+def test_reference_node_on_the_hip_engine(mods, ref_map_on_product):
+    """INTEGRATION.md §2 end to end: the reference's own surfel_map.cpp (compiled in place, unchanged) with
+    `FusionFunctions` = the product's facade, i.e. its fuse_map calls dsm_fuse_initialize_map on the GPU every frame and
+    keeps its own refill / compaction loop.  Every keyframe pose, surfel, inactive point and exported byte equals the
+    golden record of the all-CPU reference node."""
+    import test_cpu
+    api, synth, ob = mods
+    for case, gold in test_cpu._node_cases():
+        if case.get("camera") == "NODE_CAM_RGBD":
+            continue  # the reference's initialize() has no way to select its commented-out RGB-D constant set
+        test_cpu._check_node_run(case, gold, lambda cam, d: ob.RefSurfelMap(cam, drift_free_poses=d, lib_path=ref_map_on_product))
+
+
 def test_cpp_surfel_map_wrapper_replay(mods, tmp_path):
     """include/dsm_surfel_map.hpp (the reference's class / callback names over plain message structs) replaying a
     recorded message stream: the PCD and PLY it saves are the reference node's, byte for byte."""
