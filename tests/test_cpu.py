@@ -567,6 +567,82 @@ def test_node_survives_a_lost_frame_and_bounds_its_buffers(node_hostemu_lib, syn
     node.close()
 
 
+# ------------------------------------------------------------------ KITTI-layout reader
+def _write_png_grey(path, img, filters=(0, 1, 2, 3, 4)):
+    """Minimal PNG writer for the test (cycles through all five row filters so that the decoder sees each)."""
+    import struct
+    import zlib
+    h, w = img.shape
+    rows = bytearray()
+    prev = np.zeros(w, np.int32)
+    for y in range(h):
+        f = filters[y % len(filters)]
+        cur = img[y].astype(np.int32)
+        left = np.concatenate([[0], cur[:-1]])
+        ul = np.concatenate([[0], prev[:-1]])
+        if f == 0:
+            enc = cur
+        elif f == 1:
+            enc = cur - left
+        elif f == 2:
+            enc = cur - prev
+        elif f == 3:
+            enc = cur - (left + prev) // 2
+        else:
+            p = left + prev - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+            enc = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+        rows += bytes([f]) + (enc % 256).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(bytes(rows))) + chunk(b"IEND", b""))
+
+
+def test_kitti_layout_reader(synth, tmp_path):
+    """kitti_publisher's directory layout (image_0/%06d.png, depth_0/%06d.npy with depth = 386.1448 / disparity,
+    publisher.py:31-38) + a KITTI-format pose file -> the node's message stream: a synthetic sequence written in that
+    layout comes back as the messages synth.node_messages would have produced, and round-trips through a message log."""
+    from densesurfelmapping_amd import kitti, msglog
+    cam, scene = synth.NODE_CAM, synth.Scene(seed=9)
+    seq = tmp_path / "sequences" / "00"
+    (seq / "image_0").mkdir(parents=True)
+    (seq / "depth_0").mkdir()
+    n = 7
+    frames = [synth.render(cam, scene, t) for t in range(n)]
+    with open(tmp_path / "poses.txt", "w") as f:
+        for t, (img, dep, pose) in enumerate(frames):
+            _write_png_grey(str(seq / "image_0" / ("%06d.png" % t)), img)
+            with np.errstate(divide="ignore"):
+                np.save(str(seq / "depth_0" / ("%06d.npy" % t)), (kitti.BF_SEQ_00_02 / dep.astype(np.float64)).astype(np.float32))
+            f.write(" ".join("%.17g" % v for v in pose.astype(np.float64)[:3].ravel()) + "\n")
+    open(seq / "calib.txt", "w").write(f"P0: {cam.fx} 0 {cam.cx} 0 0 {cam.fy} {cam.cy} 0 0 0 1 0\n")
+    # both PNG paths: Pillow (if present) and the built-in decoder
+    raw = open(seq / "image_0" / "000003.png", "rb").read()
+    assert np.array_equal(kitti.decode_png(raw), frames[3][0]) and np.array_equal(kitti.read_grey(str(seq / "image_0" / "000003.png")), frames[3][0])
+    got_cam = kitti.camera_from_calib(str(seq), cam.width, cam.height)
+    assert (got_cam.fx, got_cam.cy) == (cam.fx, cam.cy)
+    ev = list(kitti.messages(str(seq), kitti.read_poses(str(tmp_path / "poses.txt")), keyframe_every=3))
+    assert len(ev) == 3 * n and [e[0] for e in ev[:3]] == ["image", "depth", "orb"]
+    for t in range(n):
+        img_e, dep_e, orb_e = ev[3 * t:3 * t + 3]
+        assert np.array_equal(img_e[2], frames[t][0])
+        valid = frames[t][1] > 0
+        assert np.allclose(dep_e[2][valid], frames[t][1][valid], rtol=1e-6) and (dep_e[2][~valid] == 0).all()
+        n_kf_before = (t + 2) // 3                               # keyframes at t = 0, 3, 6
+        assert orb_e[5][0] == (1.0 if t % 3 == 0 else 0.0) and orb_e[5][1] == max(n_kf_before - 1, 0)
+        assert np.allclose(orb_e[4], synth.pose7(frames[t][2]), atol=1e-12)
+        assert len(orb_e[3]) == t // 3 + 1                       # loop path = keyframes so far
+    log = str(tmp_path / "kitti.log")
+    msglog.write_log(log, got_cam, 10, iter(ev))
+    cam2, dfp, back = msglog.read_log(log)
+    back = list(back)
+    assert (cam2.width, cam2.height, dfp) == (cam.width, cam.height, 10) and len(back) == len(ev)
+    assert np.array_equal(back[4][2], ev[4][2]) and np.array_equal(back[5][3], ev[5][3])
+
+
 # ------------------------------------------------------------------ the reference's own sources on top of the product
 def test_reference_ros_node_compiles_unchanged_against_the_product(ros_node_on_product, synth, tmp_path):
     """surfel_fusion/src/ros_node.cpp (main(), the nh.subscribe / message_filters wiring, the save calls) builds against
