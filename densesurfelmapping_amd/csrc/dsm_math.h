@@ -71,7 +71,7 @@ DSM_HD float pixel_inv_depth(float d) {
 // Pixels right of / below the last cell centre by 4 or more have no candidate cell at all (only when
 // (size mod 8) > 4, e.g. KITTI's 1242x375): the reference labels them -1 and then reads and writes
 // superpixel_seeds[-1] (FF.cpp:400,442-451,242), memory in front of the vector.  Policy here (and in the
-// oracle restatement): label -1, member of no superpixel, never stable; fusion treats seed -1 as an all-zero
+// C restatement used by the tests): label -1, member of no superpixel, never stable; fusion treats seed -1 as an all-zero
 // record (the free-space test still applies, then the surfel is skipped).
 DSM_HD bool has_candidate_cell(int x, int y, int gw, int gh) { return x < gw * kCell + kCell / 2 && y < gh * kCell + kCell / 2; }
 

@@ -9,6 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -90,9 +92,7 @@ def node_hostemu_lib(oracle_built):
     return out
 
 
-REF_SRC = "/root/reference/surfel_fusion/src"
-PKG = os.path.join(ROOT, "densesurfelmapping_amd")
-_LINK = ["-L" + PKG, "-l:libdsm_hip.so", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+from ref_on_product import REF_SRC, build_ref_map_on_product, build_ros_node_on_product  # noqa: E402
 
 
 def _prebuilt_or_skip(out):
@@ -106,17 +106,9 @@ def ros_node_on_product():
     """The reference's own surfel_fusion/src/ros_node.cpp, compiled IN PLACE and UNCHANGED, with include/ros_compat in
     front of it: `SurfelMap surfel_map(nh)` and its subscriber bindings are the product's node class.  ROS itself is
     shimmed (oracle/shims + tests/ros_shims: a message pump fed from a recorded log).  Built where the reference
-    exists; the binary travels to the GPU box."""
+    exists (tests/ref_on_product.py); the binary travels to the GPU box."""
     out = os.path.join(ROOT, "tests", "_build", "ros_node_on_product")
-    if not os.path.isdir(REF_SRC):
-        return _prebuilt_or_skip(out)
-    from densesurfelmapping_amd import build
-    build.build_library()
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    _run(["g++", "-std=c++11", "-O1", "-w", "-I" + os.path.join(ROOT, "include", "ros_compat"), "-I" + os.path.join(ROOT, "tests", "ros_shims"),
-          "-I" + os.path.join(ROOT, "oracle", "shims"), os.path.join(REF_SRC, "ros_node.cpp"),
-          os.path.join(ROOT, "tests", "ros_shims", "ros_shim_bus.cpp"), "-o", out] + _LINK)
-    return out
+    return build_ros_node_on_product() if os.path.isdir(REF_SRC) else _prebuilt_or_skip(out)
 
 
 @pytest.fixture(scope="session")
@@ -125,13 +117,4 @@ def ref_map_on_product():
     include/engine_compat in front (its `#include <fusion_functions.h>` resolves to the product's facade), linked against
     libdsm_hip.so -- the reference's node class running on the HIP engine through the drop-in call."""
     out = os.path.join(ROOT, "tests", "_build", "libdsm_ref_map_on_product.so")
-    if not os.path.isdir(REF_SRC):
-        return _prebuilt_or_skip(out)
-    from densesurfelmapping_amd import build
-    build.build_library()
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    _run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++11", "-O3", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-          "-ftrivial-auto-var-init=zero", "-fno-access-control", "-w", "-DDSM_ORACLE_QUIET", "-DDSM_ORACLE_DEFERRED_THREADS",
-          "-I" + os.path.join(ROOT, "include", "engine_compat"), "-I" + os.path.join(ROOT, "oracle", "shims"), "-I" + REF_SRC,
-          "-o", out, os.path.join(ROOT, "oracle", "ref_map_driver.cpp")] + _LINK)
-    return out
+    return build_ref_map_on_product() if os.path.isdir(REF_SRC) else _prebuilt_or_skip(out)
