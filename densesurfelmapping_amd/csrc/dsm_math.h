@@ -86,16 +86,19 @@ DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, Loa
     float best_d = 1e6f, best_n = 1e6f;
     int arg_d = -1, arg_n = -1;
     bool all_depth = true;
-    for (int ox = -1; ox <= 1; ox++) {
-        const int gx = bx + ox;
-        int ax = gx * kCell + kCell / 2 - x;
-        ax = ax < 0 ? -ax : ax;
-        if (!(ax < kCell && gx >= 0 && gx < gw)) continue;
-        for (int oy = -1; oy <= 1; oy++) {
-            const int gy = by + oy;
-            int ay = gy * kCell + kCell / 2 - y;
-            ay = ay < 0 ? -ay : ay;
-            if (!(ay < kCell && gy >= 0 && gy < gh)) continue;
+    // Of the reference's 3x3 offsets at most two per axis pass its distance filter |8g+4 - x| < 8: the pixel's own
+    // cell, and the lower neighbour when x mod 8 < 4 or the upper one when x mod 8 > 4 (at x mod 8 == 4 both
+    // neighbour centres are exactly 8 away: neither).  Visiting exactly those, lower cell first, is the reference's
+    // order (x-offset outer, y-offset inner, ascending) without the offsets it skips -- and without lanes of one wave
+    // disagreeing about which of three iterations are live.
+    const int xr = x % kCell, yr = y % kCell;
+    const int gx0 = bx - (xr < kCell / 2 ? 1 : 0), gy0 = by - (yr < kCell / 2 ? 1 : 0);
+    for (int jx = 0; jx < 2; jx++) {
+        const int gx = gx0 + jx;
+        if (!(gx >= 0 && gx < gw) || (jx == 1 && xr == kCell / 2)) continue;
+        for (int jy = 0; jy < 2; jy++) {
+            const int gy = gy0 + jy;
+            if (!(gy >= 0 && gy < gh) || (jy == 1 && yr == kCell / 2)) continue;
             const int s = gy * gw + gx;
             float sx, sy, si;
             bool has_d;
