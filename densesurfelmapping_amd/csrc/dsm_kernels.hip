@@ -130,6 +130,9 @@ __device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph
 #ifndef DSM_XCD_STRIPS
 #define DSM_XCD_STRIPS 0
 #endif
+#ifndef DSM_TILED_UPDATE
+#define DSM_TILED_UPDATE 0 // experiment: k_update_seeds with its windows staged through a 24x24 LDS tile per 2x2 seeds
+#endif
 __device__ __forceinline__ int strip_blocks_per_row(int gw) { return (((gw + 3) >> 2) + 7) >> 3; }
 __device__ __forceinline__ int seed_of_block(int b, int wv, int gw, int gh) {
 #if !DSM_XCD_STRIPS
@@ -361,70 +364,10 @@ constexpr int kWin = 2 * kCell; // 16
 // APPLY (sweeps >= 1): the label image of this sweep is  new(p) = T[old(p)] < p ? pick(p) : old(p)  (see
 // k_assign); it is formed on the fly for the window, and every wave stores it for the pixels of its
 // own cell (ragged right/bottom pixels go to the last cell column/row) into the other label buffer.
-template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
-    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
-    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
-    const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
-    if (s < 0) return;
-    stamp(c, sweep, s, 0, lane);
-    const FrameParams &fp = frame_params(c);
-    const uint8_t *img = frame_image(c, fp);
-    const float *dep = frame_depth(c, fp);
-    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
-    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
-    const int w = c->w, h = c->h, pitch = c->pitch;
-    const int gx = s % c->gw, gy = s / c->gw;
-    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
-    const int t_self = c->tmin[s];
-    const float4 old = c->core[s]; // needed only after the sums: issued with the window loads, not behind them
-    float *dl = s_depth[wv], *lt = s_term[wv];
-    stamp(c, sweep, s, 1, lane);
-    int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
-    int lab[4], pi[4], cd[4], pk[4];
-    float pd[4];
-    bool pimg[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { // independent loads, one round trip
-        const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        pimg[k] = x >= 0 && x < w && y >= 0 && y < h;
-        pk[k] = pimg[k] ? y * pitch + x : 0;
-        lab[k] = label_in[pk[k]];
-        if (APPLY) cd[k] = c->cand[pk[k]];
-        pd[k] = dep[pk[k]];
-        pi[k] = (int)img[pk[k]];
-    }
-    if (APPLY) {
-        int tl[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) tl[k] = c->tmin[lab[k]];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int idx = k * 64 + lane;
-            const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-            if (tl[k] < pk[k]) lab[k] = cd[k];
-            const int ox = (x >> 3) < c->gw ? (x >> 3) : c->gw - 1, oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
-            if (pimg[k] && ox == gx && oy == gy) label_out[pk[k]] = lab[k];
-        }
-    }
-    if (t_self == kIntMax) return; // stable: FF.cpp:479-480
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
-        const bool mem = pimg[k] && x < w - 1 && y < h - 1 && lab[k] == s;
-        const float d = mem ? pd[k] : 0.0f;
-        if (mem) {
-            cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += pi[k];
-        }
-        const bool dv = mem && (double)d > 0.1; // FF.cpp:508
-        const unsigned long long m = __ballot(dv);
-        if (dv) dl[nd + rank_below(m)] = d;
-        nd += __popcll(m);
-    }
+// Second half of update_seeds for one seed (one wave): the sums of its members are in the lanes' registers, the
+// member depths > 0.1 in window row-major order in dl[0..nd).
+__device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__ c, int sweep, int s, int lane, int wx0, int wy0,
+                                                   const float4 old, float *dl, float *lt, int cnt, int sdx, int sdy, int si, int nd) {
     stamp(c, sweep, s, 2, lane);
     cnt = wave_sum(cnt);
     if (cnt == 0) { // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
@@ -489,6 +432,170 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(cons
         c->core_stage[s] = make_float4(mx, my, mi, md);
         c->stable_stage[s] = stable;
     }
+}
+
+template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
+    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
+    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
+    if (s < 0) return;
+    stamp(c, sweep, s, 0, lane);
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
+    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    const int gx = s % c->gw, gy = s / c->gw;
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+    const int t_self = c->tmin[s];
+    const float4 old = c->core[s]; // needed only after the sums: issued with the window loads, not behind them
+    float *dl = s_depth[wv], *lt = s_term[wv];
+    stamp(c, sweep, s, 1, lane);
+    int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
+    int lab[4], pi[4], cd[4], pk[4];
+    float pd[4];
+    bool pimg[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // independent loads, one round trip
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        pimg[k] = x >= 0 && x < w && y >= 0 && y < h;
+        pk[k] = pimg[k] ? y * pitch + x : 0;
+        lab[k] = label_in[pk[k]];
+        if (APPLY) cd[k] = c->cand[pk[k]];
+        pd[k] = dep[pk[k]];
+        pi[k] = (int)img[pk[k]];
+    }
+    if (APPLY) {
+        int tl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tl[k] = c->tmin[lab[k]];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = k * 64 + lane;
+            const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+            if (tl[k] < pk[k]) lab[k] = cd[k];
+            const int ox = (x >> 3) < c->gw ? (x >> 3) : c->gw - 1, oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
+            if (pimg[k] && ox == gx && oy == gy) label_out[pk[k]] = lab[k];
+        }
+    }
+    if (t_self == kIntMax) return; // stable: FF.cpp:479-480
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
+        const bool mem = pimg[k] && x < w - 1 && y < h - 1 && lab[k] == s;
+        const float d = mem ? pd[k] : 0.0f;
+        if (mem) {
+            cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += pi[k];
+        }
+        const bool dv = mem && (double)d > 0.1; // FF.cpp:508
+        const unsigned long long m = __ballot(dv);
+        if (dv) dl[nd + rank_below(m)] = d;
+        nd += __popcll(m);
+    }
+    update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
+}
+
+// The same kernel with the window loads staged through LDS (DSM_TILED_UPDATE=1): a workgroup is a 2x2 block of
+// seeds, whose four 16x16 windows cover a 24x24-pixel tile; every tile pixel is fetched (and, for APPLY, resolved to
+// its new label) once per workgroup instead of once per window -- 2.25 instead of 4 fetches per pixel over the fabric --
+// and the waves gather their windows from LDS.
+constexpr int kTile = 3 * kCell; // 24
+template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds_tiled(const DeviceCtx ctx, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
+    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
+    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
+    __shared__ int s_tl[kTile * kTile];   // label of this sweep (-1 outside the image)
+    __shared__ float s_td[kTile * kTile]; // depth
+    __shared__ int s_ti[kTile * kTile];   // intensity
+    const int tid = threadIdx.x, wv = tid >> 6, lane = lane_id();
+    const int gw = c->gw, gh = c->gh;
+    const int nbx = (gw + 1) >> 1, nby = (gh + 1) >> 1;
+    const int bb = nbx * nby - 1 - (int)blockIdx.x; // bottom rows first, see seed_of_block
+    const int bx = bb % nbx, by = bb / nbx;
+    const int gx = 2 * bx + (wv & 1), gy = 2 * by + (wv >> 1);
+    const bool live = gx < gw && gy < gh;
+    const int s = gy * gw + gx;
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
+    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    const int tx0 = 2 * kCell * bx - kCell / 2, ty0 = 2 * kCell * by - kCell / 2;
+    int t_self = kIntMax;
+    float4 old = make_float4(0, 0, 0, 0);
+    if (live) {
+        t_self = c->tmin[s];
+        old = c->core[s];
+    }
+    {
+        int l[3], cd[3], pi[3], pp[3];
+        float d[3];
+        bool in[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { // independent loads, one round trip
+            const int idx = q * 256 + tid;
+            const int x = tx0 + idx % kTile, y = ty0 + idx / kTile;
+            in[q] = idx < kTile * kTile && x >= 0 && x < w && y >= 0 && y < h;
+            pp[q] = in[q] ? y * pitch + x : 0;
+            l[q] = label_in[pp[q]];
+            if (APPLY) cd[q] = c->cand[pp[q]];
+            d[q] = dep[pp[q]];
+            pi[q] = (int)img[pp[q]];
+        }
+        if (APPLY) {
+            int tl[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) tl[q] = c->tmin[l[q] >= 0 ? l[q] : 0];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int idx = q * 256 + tid;
+                const int x = tx0 + idx % kTile, y = ty0 + idx / kTile;
+                if (l[q] >= 0 && tl[q] < pp[q]) l[q] = cd[q];
+                // every pixel of the block's 2x2 cells is stored by this block (ragged right / bottom pixels belong to the last cells)
+                const int ox = (x >> 3) < gw ? (x >> 3) : gw - 1, oy = (y >> 3) < gh ? (y >> 3) : gh - 1;
+                if (in[q] && (ox >> 1) == bx && (oy >> 1) == by) label_out[pp[q]] = l[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int idx = q * 256 + tid;
+            if (idx < kTile * kTile) {
+                s_tl[idx] = in[q] ? l[q] : -1;
+                s_td[idx] = d[q];
+                s_ti[idx] = pi[q];
+            }
+        }
+    }
+    __syncthreads();
+    if (!live || t_self == kIntMax) return; // stable: FF.cpp:479-480
+    stamp(c, sweep, s, 0, lane);
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+    float *dl = s_depth[wv], *lt = s_term[wv];
+    int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        const int t = (y - ty0) * kTile + (x - tx0);
+        // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
+        const bool mem = s_tl[t] == s && x < w - 1 && y < h - 1;
+        const float d = mem ? s_td[t] : 0.0f;
+        if (mem) {
+            cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += s_ti[t];
+        }
+        const bool dv = mem && (double)d > 0.1; // FF.cpp:508
+        const unsigned long long m = __ballot(dv);
+        if (dv) dl[nd + rank_below(m)] = d;
+        nd += __popcll(m);
+    }
+    update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
 }
 
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
@@ -1449,6 +1556,8 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     const dim3 g_seed_wave((S + 3) / 4);
 #endif
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
+    const dim3 g_seed_tile(((hc.gw + 1) / 2) * ((hc.gh + 1) / 2));
+    (void)g_seed_tile;
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
     hipLaunchStage(k_init_seeds, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256), 0, st, hc);
@@ -1457,14 +1566,22 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
         if (sweep == 0) {
             hipLaunchStage(k_assign<true>, g_tile, dim3(256), 0, st, hc, sweep);
             DSM_MARK();
+#if DSM_TILED_UPDATE
+            hipLaunchStage(k_update_seeds_tiled<false>, g_seed_tile, dim3(256), 0, st, hc, sweep);
+#else
             hipLaunchStage(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, hc, sweep);
+#endif
             DSM_MARK();
         } else {
             hipLaunchStage(k_assign<false>, g_tile, dim3(256), 0, st, hc, sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve, dim3(1), dim3(256), 0, st, hc, sweep);
             DSM_MARK();
+#if DSM_TILED_UPDATE
+            hipLaunchStage(k_update_seeds_tiled<true>, g_seed_tile, dim3(256), 0, st, hc, sweep);
+#else
             hipLaunchStage(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, hc, sweep);
+#endif
             DSM_MARK();
         }
         hipLaunchStage(k_commit_seeds, g_seed_thr, dim3(256), 0, st, hc, sweep);
