@@ -30,7 +30,11 @@ def run_case(case, make_node, checkpoint_every=10):
     node = make_node(cam, case["drift_free_poses"])
     briefs, checkpoints = [], {}
     n_orb = 0
-    for ev in synth.node_messages(cam, scene, case["frames"], **case["kw"]):
+    kw = dict(case["kw"])
+    if cam.width * cam.height > 200_000:  # big frames: render the lap once, on worker processes, cached in /tmp
+        lap = kw.get("lap", 40)
+        kw["frames"] = dict(enumerate(synth.render_many([(cam, scene, t) for t in range(lap)])))
+    for ev in synth.node_messages(cam, scene, case["frames"], **kw):
         node.feed(ev)
         if ev[0] == "orb":
             briefs.append(node_state.brief(node))
@@ -57,6 +61,13 @@ def main():
         np.savez_compressed(os.path.join(HERE, fname), **final)
         out["cases"].append({"name": case["name"], "briefs": briefs, "checkpoints": checkpoints, "final": fname,
                              "final_digest": node_state.digest(final), "files": files})
+        print(case["name"], "fused/poses/local/inactive:", briefs[-1], "pcd bytes", files["pcd"]["bytes"], "ply bytes", files["ply"]["bytes"])
+    out["large_cases"] = []
+    for case in node_state.SCENARIOS_LARGE:
+        briefs, checkpoints, final, files = run_case(case, lambda cam, d: RefSurfelMap(cam, drift_free_poses=d))
+        out["large_cases"].append({"name": case["name"], "briefs": briefs, "checkpoints": checkpoints, "final": None,
+                                   "final_digest": node_state.digest(final), "files": files,
+                                   "final_counts": {k: int(len(v)) for k, v in final.items()}})
         print(case["name"], "fused/poses/local/inactive:", briefs[-1], "pcd bytes", files["pcd"]["bytes"], "ply bytes", files["ply"]["bytes"])
     with open(os.path.join(HERE, "node_golden.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -20,6 +20,14 @@ SCENARIOS = [
      "kw": {"lap": 32, "keyframe_every": 4, "drift_rate": 0.1}},
 ]
 
+# At the headline resolution (BASELINE configs[1]/[2] through the node): a lap of 50 frames at 1226x370, loop closure at
+# the start of the second lap with ~50 k inactive surfels on 10 keyframes to warp, re-activation, a lagging loop path.
+# Digests only (the final state is tens of MB).
+SCENARIOS_LARGE = [
+    {"name": "kitti_circuit_130", "frames": 130, "drift_free_poses": 4, "camera": "KITTI_1226", "scene": {"seed": 12345},
+     "kw": {"lap": 50, "path_lag": 1, "extra_loops": {90: [(14, 3)]}}},
+]
+
 
 def camera_and_scene(case, synth):
     return getattr(synth, case.get("camera", "NODE_CAM")), synth.Scene(**case.get("scene", {}))

@@ -185,3 +185,15 @@ def test_fullhd_2m_fuse_and_warp(mods, gold):
     assert fields_equal(s, store.astype(api.SURFEL_DTYPE)) == []
     assert np.array_equal(c.view("u4"), cloud.view("u4"))
     ff.close()
+
+
+def test_node_at_kitti_resolution(mods):
+    """The whole node on the GPU at the headline resolution (130 frames at 1226x370 through the message callbacks: stamp
+    matching, pose graph, active / inactive sets in HBM, loop closure with the warp of ~50 k inactive surfels on ten
+    keyframes and of the active map, re-activation) against digests recorded from the reference's own surfel_map.cpp:
+    counts after every pose message, the whole state every ten, the final state and the saved PCD / PLY."""
+    import test_cpu
+    from densesurfelmapping_amd import surfel_map
+    for case, gold in test_cpu._node_cases_large():
+        assert gold["briefs"][-1][3] > 20000, "the scenario no longer builds a sizeable inactive set"
+        test_cpu._check_node_run(case, gold, lambda cam, d: surfel_map.SurfelMap(cam, drift_free_poses=d, surfel_capacity=1 << 20))
