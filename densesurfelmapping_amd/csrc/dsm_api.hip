@@ -47,56 +47,69 @@ class HostPool {
         cv_.notify_all();
         for (std::thread &t : workers_) t.join();
     }
-    // fn(i) for i in [0, n): the caller takes part
+    // fn(i) for i in [0, n): the caller takes part.  A job lives on the caller's stack; workers pin it (users) under
+    // the lock before touching it and the caller leaves only when every task is done and nobody holds the job any more,
+    // so a worker that wakes late finds either the live job or none.
     void run(int n, const std::function<void(int)> &fn) {
         if (n <= 1 || workers_.empty()) {
             for (int i = 0; i < n; i++) fn(i);
             return;
         }
+        Job job;
+        job.fn = &fn;
+        job.n = n;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &fn;
-            next_.store(0);
-            n_ = n;
-            done_ = 0;
+            job_ = &job;
             gen_++;
         }
         cv_.notify_all();
-        work();
+        help(job);
         std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return done_ == n_; });
-        fn_ = nullptr;
+        done_cv_.wait(lk, [&] { return job.done.load() == n && job.users == 0; });
+        job_ = nullptr;
     }
-    int width() const { return (int)workers_.size() + 1; }
 
   private:
-    void work() {
+    struct Job {
+        const std::function<void(int)> *fn = nullptr;
+        int n = 0;
+        std::atomic<int> next{0}, done{0};
+        int users = 0; // guarded by mu_
+    };
+    void help(Job &job) {
         for (;;) {
-            const int i = next_.fetch_add(1);
-            if (i >= n_) return;
-            (*fn_)(i);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (++done_ == n_) done_cv_.notify_all();
+            const int i = job.next.fetch_add(1);
+            if (i >= job.n) return;
+            (*job.fn)(i);
+            if (job.done.fetch_add(1) + 1 == job.n) {
+                std::lock_guard<std::mutex> lk(mu_);
+                done_cv_.notify_all();
+            }
         }
     }
     void loop() {
         unsigned seen = 0;
         for (;;) {
+            Job *job;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
                 if (stop_) return;
                 seen = gen_;
+                job = job_;
+                if (job) job->users++;
             }
-            work();
+            if (!job) continue;
+            help(*job);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--job->users == 0) done_cv_.notify_all();
         }
     }
     std::vector<std::thread> workers_;
     std::mutex mu_;
     std::condition_variable cv_, done_cv_;
-    const std::function<void(int)> *fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_ = 0, done_ = 0;
+    Job *job_ = nullptr;
     unsigned gen_ = 0;
     bool stop_ = false;
 };
