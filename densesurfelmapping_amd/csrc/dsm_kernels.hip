@@ -1319,11 +1319,133 @@ __device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c, in
 // Frame tail in one workgroup: new surfels (ordered), deleted-slot list, order-exact compaction, then
 // commit the map size and bump the params cursor.  The phases are separated by a workgroup-scope fence +
 // barrier because later phases read what earlier ones (same workgroup) wrote to global memory.
+//
+// Fast path (S <= 8192 seeds, M <= 262144 surfels: every KITTI / VGA frame): the kernel is a chain of dependent trips to
+// memory, so everything it needs is fetched in ONE trip -- the two byte planes of the spawn test and this thread's four
+// words of the hole bitmap (thread t owns words 4t .. 4t+3: one block scan orders all holes) -- the spawn list and the
+// refill targets stay in LDS, and the only second trip is the prepared records themselves.  The rare K < k frame (more
+// deleted slots than new surfels: swap-with-last chains) and larger frames / maps take the general path below.
+constexpr int kTailFastSeeds = 8192, kTailFastWords = 4096;
+
+__device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c, int with_compaction, int *s_idx /* [8192] */,
+                                                int *s_refill /* [8192] */, int *s_cnt /* [129] */, int *s_wave /* [17] */, int &M_out) {
+    const int S = c->n_seed, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    // ---- one trip: the map size, the spawn planes and the hole bitmap (words beyond the map are dropped once the size
+    // is known; the bitmap allocation holds cap / 64 + 1 words)
+    unsigned char ok[8], fu[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int sd = q * 1024 + tid;
+        ok[q] = c->spawn_ok[sd < S ? sd : 0];
+        fu[q] = c->fused_flag[sd < S ? sd : 0];
+    }
+    unsigned long long mk[4] = {0, 0, 0, 0};
+    if (with_compaction) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (4 * tid + q <= c->cap / 64) mk[q] = c->hole_mask[4 * tid + q];
+    }
+    const int M = c->n_local[0];
+    M_out = M;
+    if (M > kTailFastWords * 64) return false;
+    const int n_word = (M + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (4 * tid + q >= n_word) mk[q] = 0;
+    // ---- spawn list (seed order = round-major, then thread) into LDS
+    unsigned mine = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const bool spawn = q * 1024 + tid < S && ok[q] && !fu[q];
+        if (spawn) mine |= 1u << q;
+        const unsigned long long m = __ballot(spawn);
+        if (lane == 0) s_cnt[q * 16 + wv] = __popcll(m);
+    }
+    __syncthreads();
+    if (wv == 0) { // exclusive scan of the 128 wave counts by wave 0
+        int run = 0;
+#pragma unroll
+        for (int base = 0; base < 128; base += 64) {
+            const int v = s_cnt[base + lane];
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            s_cnt[base + lane] = run + inc - v;
+            run += __shfl(inc, 63);
+        }
+        if (lane == 0) s_cnt[128] = run;
+    }
+    // ---- holes: one scan over the per-thread counts (thread t's words precede thread t+1's)
+    int excl = 0, k = 0;
+    if (with_compaction) {
+        const int cnt = __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
+        k = block_scan_1024(cnt, excl, s_wave); // (its barriers also publish s_cnt)
+    } else {
+        __syncthreads();
+    }
+    const int K = s_cnt[128];
+    if (with_compaction && K < k) return false; // general path (nothing has been written yet)
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const bool spawn = (mine >> q) & 1u;
+        const unsigned long long m = __ballot(spawn);
+        if (spawn) s_idx[s_cnt[q * 16 + wv] + rank_below(m)] = q * 1024 + tid;
+    }
+    if (with_compaction) { // new surfel j goes to hole D[k-1-j] (SM.cpp:1087-1102): the hole of rank o takes j = k-1-o
+        int o = excl;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned long long m = mk[q];
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                s_refill[k - 1 - o] = (4 * tid + q) * 64 + b;
+                o++;
+                m &= m - 1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the prepared records to their places
+    const dsm_surfel *rec = c->spawn_rec;
+    if (with_compaction) {
+        int new_m = M + (K - k);
+        if (new_m > c->cap) { // cannot append: report, keep what fits
+            if (tid == 0) atomicOr(c->status, kStatusCapacity);
+            new_m = c->cap;
+        }
+        for (int j = tid; j < K; j += 1024) {
+            const int tgt = j < k ? s_refill[j] : M + (j - k);
+            if (tgt < c->cap) c->local[tgt] = rec[s_idx[j]];
+        }
+        if (tid == 0) {
+            c->n_holes[0] = k;
+            c->n_local[0] = new_m;
+        }
+    } else { // FusionFunctions::fuse_initialize_map hands the new surfels back separately
+        for (int j = tid; j < K; j += 1024) c->fresh[j] = rec[s_idx[j]];
+    }
+    if (tid == 0) {
+        c->n_new[0] = K;
+        c->cursor[0] = c->cursor[0] + 1;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, int with_compaction) {
     const DeviceCtx *__restrict__ c = &ctx;
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
-    const int M = c->n_local[0];
+    __shared__ int s_idx[kTailFastSeeds], s_refill[kTailFastSeeds];
+    int M = 0;
+    if (c->n_seed <= kTailFastSeeds) {
+        if (frame_tail_fast(c, with_compaction, s_idx, s_refill, s_cnt, s_wave, M)) return;
+        __syncthreads(); // K < k, or a larger map: start over on the general path
+    } else {
+        M = c->n_local[0];
+    }
     const int K = tail_spawn_list(c, s_cnt);
     int k = 0;
     if (with_compaction) k = tail_hole_scan(c, s_wave, M);
