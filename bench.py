@@ -157,6 +157,11 @@ def main():
                     help="independent subsequences (handles/streams) per GPU")
     ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSM_BENCH_FRAMES_PER_STEP", "32")),
                     help="frames every subsequence advances per step")
+    ap.add_argument("--mode", choices=("batched", "streams"), default=os.environ.get("DSM_BENCH_MODE", "batched"),
+                    help="batched: the B subsequences advance in lockstep, one launch per kernel for all of them (dsm_batch_*); "
+                         "streams: B handles on B streams, the hardware queues overlap their kernels (round 1's mode)")
+    ap.add_argument("--batches", type=int, default=int(os.environ.get("DSM_BENCH_BATCHES", "1")),
+                    help="batched mode: split the B subsequences into this many batches, each on its own stream")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("DSM_BENCH_HOST_THREADS", "4")),
                     help="host threads enqueueing graph replays (each drives streams/threads handles)")
     ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("DSM_BENCH_PIPELINE_DEPTH", "0")),
@@ -231,7 +236,7 @@ def main():
     # subsequences advance together.
     from concurrent.futures import ThreadPoolExecutor
     n_thr = max(1, min(args.host_threads, B))
-    pool = ThreadPoolExecutor(n_thr)
+    pool = ThreadPoolExecutor(max(n_thr, args.batches))
     enqueue_s = [0.0]
 
     def drive(group, lo, hi, chunk):
@@ -241,10 +246,23 @@ def main():
                 s, r, p = plans[b]
                 handles[b].replay_enqueue(s[c0:c1], r[c0:c1], p[c0:c1])
 
+    n_bat = max(1, min(args.batches, B)) if args.mode == "batched" else 0
+    groups_b = [list(range(g, B, n_bat)) for g in range(n_bat)]
+    batches = [api.Batch([handles[b] for b in grp]) for grp in groups_b]
+
+    def drive_batch(g, lo, hi, chunk):
+        for c0 in range(lo, hi, chunk):
+            c1 = min(hi, c0 + chunk)
+            s, r, p, n = api.Batch.pack([(plans[b][0][c0:c1], plans[b][1][c0:c1], plans[b][2][c0:c1]) for b in groups_b[g]])
+            batches[g].replay_enqueue(s, r, p, n)
+
     def run(lo, hi, chunk=64):
         t_e = time.perf_counter()
-        groups = [list(range(t, B, n_thr)) for t in range(n_thr)]
-        list(pool.map(lambda g: drive(g, lo, hi, chunk), groups))
+        if batches:
+            list(pool.map(lambda g: drive_batch(g, lo, hi, chunk), range(n_bat)))
+        else:
+            groups = [list(range(t, B, n_thr)) for t in range(n_thr)]
+            list(pool.map(lambda g: drive(g, lo, hi, chunk), groups))
         enqueue_s[0] = time.perf_counter() - t_e
 
     def sync_all():
@@ -283,6 +301,8 @@ def main():
         merged, counts = merge_clouds(torch.cat(clouds).to(coll_dev))
         merged_total = int(sum(counts))
 
+    for bt in batches:
+        bt.close()
     for ff in handles:  # the extra measurements below run alone on the GPU
         ff.close()
     handles = []
@@ -297,6 +317,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: synthetic KITTI-shaped replay 1226x370, full superpixel+normal+"
                                "fuse+compaction HIP path, frames and map resident in HBM",
+                   "launch_mode": (f"batched: {n_bat} batch(es) of subsequences advancing in lockstep, every kernel launched once per batch"
+                                   if args.mode == "batched" else "streams: one handle and stream per subsequence"),
                    "subsequences_per_gpu": B, "frames_per_subsequence_per_step": F, "frames_per_step_per_gpu": B * F,
                    "timed_frame_indices": [lo_t, hi_t - 1], "host_enqueue_threads": n_thr,
                    "pipeline_depth": args.pipeline_depth or 1,

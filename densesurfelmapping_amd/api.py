@@ -50,6 +50,8 @@ ABI_SYMBOLS = (
     "dsm_store_download",
     "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
+    "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
+    "dsm_batch_replay_timed",
     "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps",
     "dsm_debug_run_stages", "dsm_debug_get_label_buffer", "dsm_debug_set_label_buffer", "dsm_debug_get_seed_state",
     "dsm_debug_set_seed_state",
@@ -136,6 +138,14 @@ def load_library():
     lib.dsm_debug_get_seed_state.argtypes = [_vp, _vp, _vp]
     lib.dsm_debug_set_seed_state.argtypes = [_vp, _vp, _vp]
     lib.dsm_replay_timed.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.POINTER(_StageTimes)]
+    lib.dsm_batch_create.argtypes = [C.POINTER(_vp), C.c_int32, C.POINTER(_vp)]
+    lib.dsm_batch_destroy.argtypes = [_vp]
+    lib.dsm_batch_destroy.restype = None
+    lib.dsm_batch_last_error.argtypes = [_vp]
+    lib.dsm_batch_last_error.restype = C.c_char_p
+    lib.dsm_batch_replay_enqueue.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
+    lib.dsm_batch_synchronize.argtypes = [_vp]
+    lib.dsm_batch_replay_timed.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.POINTER(_StageTimes)]
     _lib = lib
     return lib
 
@@ -428,4 +438,60 @@ class FusionFunctions:
         self.event_overhead_ms = st.event_overhead_ms / max(st.frames, 1)
         self.timed_mean_new = st.sum_new / max(st.frames, 1)      # K: surfels created per frame
         self.timed_mean_local = st.sum_local / max(st.frames, 1)  # M: live surfels after a frame
+        return {st.name[i].decode(): (st.ms[i], st.launches[i]) for i in range(st.n_stages)}, st.frames
+
+
+class Batch:
+    """Handles of equal image size on one device advancing in lockstep: every kernel of a frame is launched once for all
+    of them (include/dsm.h, dsm_batch_*).  The handles keep their own maps and frame slots and stay usable on their own
+    (map_download, labels, ...) between batch calls."""
+
+    def __init__(self, handles):
+        self._lib = load_library()
+        self.handles = list(handles)
+        arr = (_vp * len(self.handles))(*[h._h for h in self.handles])
+        b = _vp()
+        rc = self._lib.dsm_batch_create(arr, len(self.handles), C.byref(b))
+        if rc:
+            raise DsmError(rc, self._lib.dsm_batch_last_error(None).decode())
+        self._b = b
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self._lib.dsm_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise DsmError(rc, self._lib.dsm_batch_last_error(self._b).decode())
+
+    @staticmethod
+    def pack(plans):
+        """[(slots[n], ref_idx[n], poses_cm[n,16]) per handle] (FusionFunctions.pack_replay) -> handle-major arrays."""
+        n = len(plans[0][0])
+        assert all(len(p[0]) == n for p in plans), "every handle of a batch advances by the same number of frames"
+        return (np.ascontiguousarray(np.concatenate([p[0] for p in plans]), np.int32),
+                np.ascontiguousarray(np.concatenate([p[1] for p in plans]), np.int32),
+                np.ascontiguousarray(np.concatenate([p[2] for p in plans]), np.float32), n)
+
+    def replay_enqueue(self, slots, ref_idx, poses_cm, n_frames):
+        self._check(self._lib.dsm_batch_replay_enqueue(self._b, n_frames, _ptr(slots), _ptr(ref_idx), _ptr(poses_cm)))
+
+    def synchronize(self):
+        self._check(self._lib.dsm_batch_synchronize(self._b))
+
+    def replay_timed(self, slots, ref_idx, poses_cm, n_frames):
+        """Eager batched replay with a HIP event pair around every (batched) kernel; returns {stage: (ms_total, launches)}
+        and the number of handle-frames."""
+        st = _StageTimes()
+        self._check(self._lib.dsm_batch_replay_timed(self._b, n_frames, _ptr(slots), _ptr(ref_idx), _ptr(poses_cm), C.byref(st)))
+        self.event_overhead_ms = st.event_overhead_ms / max(st.frames, 1)
+        self.timed_mean_new = st.sum_new / max(st.frames, 1)
+        self.timed_mean_local = st.sum_local / max(st.frames, 1)
         return {st.name[i].decode(): (st.ms[i], st.launches[i]) for i in range(st.n_stages)}, st.frames

@@ -1260,7 +1260,211 @@ int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
     return DSM_OK;
 }
 
+} // extern "C"
+
+// ------------------------------------------------------------------ batches
+struct dsm_batch {
+    std::vector<dsm_handle *> hs;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceCtx *d_ctxs = nullptr;
+    hipGraphExec_t graph = nullptr;
+    hipEvent_t ev_out = nullptr;
+    hipEvent_t ev[kNumStages + 2];
+    bool have_events = false;
+    int cap_max = 0;
+    std::string err;
+};
+
+namespace {
+thread_local std::string g_batch_create_error;
+
+int bfail(dsm_batch *b, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (b) b->err = buf; else g_batch_create_error = buf;
+    return code;
+}
+#define BHIP_TRY(b, expr)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return bfail(b, DSM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+// params of frames [i0, i0+m) of every handle go up on the handles' own streams; the batch stream waits for them
+int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
+    for (size_t j = 0; j < b->hs.size(); j++) {
+        dsm_handle *h = b->hs[j];
+        if (!h->map_valid) return bfail(b, DSM_E_STATE, "handle %zu has no resident map: call dsm_map_upload first (n may be 0)", j);
+        const size_t o = j * (size_t)n_frames + (size_t)i0;
+        int staged = 0;
+        const int rc = stage_params_batch(h, m, slots + o, ref_idx + o, poses16 + 16 * o, &staged);
+        if (rc) return bfail(b, rc, "handle %zu: %s", j, h->err.c_str());
+        if (staged != m) return bfail(b, DSM_E_STATE, "handle %zu: parameter rings of the batch are out of step", j);
+        BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
+        BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
+    }
+    return DSM_OK;
+}
+// the handles' bookkeeping after m frames were enqueued on the batch stream; their streams wait for the batch
+int batch_advance(dsm_batch *b, int m) {
+    BHIP_TRY(b, hipEventRecord(b->ev_out, b->stream));
+    for (dsm_handle *h : b->hs) {
+        BHIP_TRY(b, hipStreamWaitEvent(h->stream, b->ev_out, 0));
+        h->shadow_n = -1;
+        h->frames_submitted += m;
+        const int64_t up = (int64_t)h->map_upper + (int64_t)m * h->hc.n_seed;
+        h->map_upper = up > h->hc.cap ? h->hc.cap : (int)up;
+        h->fence_pending = true;
+    }
+    return DSM_OK;
+}
+} // namespace
+
+extern "C" {
+
+const char *dsm_batch_last_error(const dsm_batch *b) { return b ? b->err.c_str() : g_batch_create_error.c_str(); }
+
+int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
+    if (!handles || !out || n < 1 || n > 1024) return bfail(nullptr, DSM_E_INVALID, "bad batch arguments");
+    *out = nullptr;
+    for (int j = 0; j < n; j++) {
+        const dsm_handle *h = handles[j];
+        if (!h) return bfail(nullptr, DSM_E_INVALID, "null handle");
+        if (h->n_pipe != 1) return bfail(nullptr, DSM_E_INVALID, "handles of a batch need pipeline_depth 1");
+        if (h->device != handles[0]->device || h->hc.w != handles[0]->hc.w || h->hc.h != handles[0]->hc.h)
+            return bfail(nullptr, DSM_E_INVALID, "handles of a batch must share device and image size");
+        if (h->frames_submitted % kParamRing != handles[0]->frames_submitted % kParamRing)
+            return bfail(nullptr, DSM_E_STATE, "handles of a batch must have fused the same number of frames (their parameter rings advance together)");
+    }
+    dsm_batch *b = new (std::nothrow) dsm_batch();
+    if (!b) return bfail(nullptr, DSM_E_HIP, "out of host memory");
+    b->hs.assign(handles, handles + n);
+    b->device = handles[0]->device;
+    auto bail = [&](int code) {
+        g_batch_create_error = b->err;
+        dsm_batch_destroy(b);
+        return code;
+    };
+#define BCREATE_TRY(expr)                                                       \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            bfail(b, DSM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+            return bail(DSM_E_HIP);                                             \
+        }                                                                       \
+    } while (0)
+    BCREATE_TRY(hipSetDevice(b->device));
+    BCREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    BCREATE_TRY(hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming));
+    for (int i = 0; i <= kNumStages + 1; i++) BCREATE_TRY(hipEventCreate(&b->ev[i]));
+    b->have_events = true;
+    std::vector<DeviceCtx> ctxs((size_t)n);
+    for (int j = 0; j < n; j++) {
+        ctxs[(size_t)j] = handles[j]->pipe[0].ctx;
+        b->cap_max = std::max(b->cap_max, handles[j]->hc.cap);
+    }
+    BCREATE_TRY(hipMalloc((void **)&b->d_ctxs, sizeof(DeviceCtx) * (size_t)n));
+    BCREATE_TRY(hipMemcpy(b->d_ctxs, ctxs.data(), sizeof(DeviceCtx) * (size_t)n, hipMemcpyHostToDevice));
+#undef BCREATE_TRY
+    *out = b;
+    return DSM_OK;
+}
+
+void dsm_batch_destroy(dsm_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->graph) (void)hipGraphExecDestroy(b->graph);
+    if (b->ev_out) (void)hipEventDestroy(b->ev_out);
+    if (b->have_events)
+        for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(b->ev[i]);
+    if (b->d_ctxs) (void)hipFree(b->d_ctxs);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
+    if (!b) return DSM_E_INVALID;
+    if (n_frames < 0 || (n_frames > 0 && (!slots || !ref_idx || !poses16))) return bfail(b, DSM_E_INVALID, "null/negative argument");
+    BHIP_TRY(b, hipSetDevice(b->device));
+    dsm_handle *h0 = b->hs[0];
+    for (int i = 0; i < n_frames;) {
+        int m = n_frames - i;
+        const int ring = (int)(h0->frames_submitted % kParamRing);
+        if (m > kParamRing - ring) m = kParamRing - ring;
+        if (m > kParamRing / 2) m = kParamRing / 2;
+        int rc = batch_stage(b, n_frames, i, m, slots, ref_idx, poses16);
+        if (rc) return rc;
+        if (!b->graph) {
+            hipGraph_t g = nullptr;
+            BHIP_TRY(b, hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+            const hipError_t le = launch_frame(h0->pipe[0].ctx, b->cap_max, true, b->stream, nullptr, 0, kNumStages - 1, b->d_ctxs, (int)b->hs.size());
+            const hipError_t ce = hipStreamEndCapture(b->stream, &g);
+            if (le != hipSuccess) return bfail(b, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
+            if (ce != hipSuccess) return bfail(b, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+            const hipError_t ie = hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (ie != hipSuccess) return bfail(b, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        }
+        for (int f = 0; f < m; f++) BHIP_TRY(b, hipGraphLaunch(b->graph, b->stream));
+        if ((rc = batch_advance(b, m))) return rc;
+        i += m;
+    }
+    return DSM_OK;
+}
+
+int dsm_batch_synchronize(dsm_batch *b) {
+    if (!b) return DSM_E_INVALID;
+    BHIP_TRY(b, hipSetDevice(b->device));
+    for (size_t j = 0; j < b->hs.size(); j++) {
+        const int rc = sync_and_fetch_counts(b->hs[j]);
+        if (rc) return bfail(b, rc, "handle %zu: %s", j, b->hs[j]->err.c_str());
+    }
+    return DSM_OK;
+}
+
+int dsm_batch_replay_timed(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
+                           dsm_stage_times *out) {
+    if (!b || !out) return DSM_E_INVALID;
+    if (n_frames < 0 || (n_frames > 0 && (!slots || !ref_idx || !poses16))) return bfail(b, DSM_E_INVALID, "null/negative argument");
+    BHIP_TRY(b, hipSetDevice(b->device));
+    out->n_stages = kNumStages;
+    for (int s = 0; s < kNumStages; s++) out->name[s] = kStageNames[s];
+    dsm_handle *h0 = b->hs[0];
+    const int n = (int)b->hs.size();
+    for (int i = 0; i < n_frames; i++) {
+        int rc = batch_stage(b, n_frames, i, 1, slots, ref_idx, poses16);
+        if (rc) return rc;
+        const hipError_t e = launch_frame(h0->pipe[0].ctx, b->cap_max, true, b->stream, b->ev, 0, kNumStages - 1, b->d_ctxs, n);
+        if (e != hipSuccess) return bfail(b, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+        if ((rc = batch_advance(b, 1))) return rc;
+        if ((rc = dsm_batch_synchronize(b))) return rc;
+        for (int s = 0; s < kNumStages; s++) {
+            float ms = 0.0f;
+            BHIP_TRY(b, hipEventElapsedTime(&ms, b->ev[s], b->ev[s + 1]));
+            out->ms[s] += (double)ms;
+            out->launches[s] += 1;
+        }
+        float cal = 0.0f;
+        BHIP_TRY(b, hipEventElapsedTime(&cal, b->ev[kNumStages], b->ev[kNumStages + 1]));
+        out->event_overhead_ms += (double)cal * n; // (per handle-frame, like `frames`)
+        out->frames += n;
+        for (dsm_handle *h : b->hs) {
+            out->sum_new += h->h_scalars[1];
+            out->sum_local += h->h_scalars[0];
+        }
+    }
+    return DSM_OK;
+}
+
+} // extern "C"
+
 // ------------------------------------------------------------------ per-kernel timing
+extern "C" {
 
 int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
                      dsm_stage_times *out) {

@@ -110,7 +110,8 @@ constexpr int kNumStages = 16;
 constexpr int kLastSuperpixelStage = 13; // init_seeds .. seed_fit need the frame only; fuse_surfels + frame_tail need the map
 extern const char *const kStageNames[kNumStages];
 hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_compaction,
-                        hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1);
+                        hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1,
+                        const DeviceCtx *d_batch = nullptr, int n_batch = 1);
 
 struct WarpMat {
     float m[16]; // column-major 4x4

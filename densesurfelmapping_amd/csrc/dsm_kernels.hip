@@ -160,8 +160,8 @@ __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const Fr
 // is needed is only known once the centre has arrived, and a second dependent round trip costs more than the 1 KB
 // per seed read from L2); the first hit is the lowest lane with one: one ballot per wave.
 constexpr int kInitLanes = 16, kInitSeedsPerBlock = 256 / kInitLanes;
-__global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     const int tid = threadIdx.x, lane = lane_id();
     const int r = tid & (kInitLanes - 1);
     const int s = blockIdx.x * kInitSeedsPerBlock + tid / kInitLanes;
@@ -256,8 +256,8 @@ __device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
     }
 }
 
-template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
     const FrameParams &fp = frame_params(c);
@@ -320,8 +320,8 @@ template <bool FIRST> __global__ __launch_bounds__(256) void k_assign(const Devi
 // One workgroup iterates the worklist to the fixed point.  (Folding this into k_assign behind a
 // "last block done" ticket costs a device-scope release per workgroup -- an L2 write-back on this
 // multi-XCD part -- and was 10x slower than the extra launch.)
-__global__ __launch_bounds__(256) void k_resolve(const DeviceCtx ctx, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(256) void k_resolve(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     resolve_worklist(c, ((sweep - 1) & 1) ? c->label_alt : c->label);
 }
 
@@ -434,8 +434,8 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
     }
 }
 
-template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -506,8 +506,8 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds(cons
 // its new label) once per workgroup instead of once per window -- 2.25 instead of 4 fetches per pixel over the fabric --
 // and the waves gather their windows from LDS.
 constexpr int kTile = 3 * kCell; // 24
-template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds_tiled(const DeviceCtx ctx, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds_tiled(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     __shared__ int s_tl[kTile * kTile];   // label of this sweep (-1 outside the image)
@@ -599,8 +599,8 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds_tile
 }
 
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
-__global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s == 0) c->work_count[0] = 0;
     if (s >= c->n_seed) return;
@@ -642,8 +642,8 @@ constexpr int kCols = 6; // LDS columns per wave of k_seed_points, reused across
 // columns at the same element offset (ds_read_b128) do not collide
 constexpr int kColStride = kWin * kWin + 4;
 
-__global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
@@ -778,14 +778,18 @@ __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx) {
 }
 
 // ---- the fit: four seeds per wave, sixteen lanes per seed
-// LDS columns per seed: p0 | p1 | p2 | ones | residual, padded with +0.0f up to the longest list of the four (a
+// LDS columns per seed: p0 | p1 | p2 | residual, padded with +0.0f up to the longest list of the four (a
 // running sum that starts at +0.0 stays bit-identical when +0.0 is added, and a padded element's product is +0.0).
-constexpr int kFitSeeds = 4, kFitLanes = 16, kFitCols = 5;
+constexpr int kFitSeeds = 4, kFitLanes = 16, kFitCols = 4;
 constexpr int kFitStride = kGnCap + 4; // 236 floats: successive columns 16 B x 59 apart -> shifted by 11 x 16 B mod 256
-// accumulator of lane gl of a group: (X column, Y column); columns 0..2 = p, 3 = ones, 4 = residual.
-// gl 0..9 = H(a,b), a <= b; gl 10..13 = J(a); gl 14, 15 idle (they stream ones x ones and are ignored)
-__constant__ const signed char kFitX[16] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 4, 4, 4, 4, 3, 3};
-__constant__ const signed char kFitY[16] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3, 0, 1, 2, 3, 3, 3};
+// accumulator of lane gl of a group: (X column, Y column); columns 0..2 = p, 3 = residual, 4 = the homogeneous 1 -- a
+// shared block of eight 1.0f read at stride 0 instead of a column per seed (LDS per wave decides how many waves a CU
+// holds, and this kernel is short of waves).  gl 0..8 = H(a,b), a <= b, without H(3,3); gl 9 = H(3,3) = 2 x (number of
+// core elements), an integer that needs no sum; gl 10..13 = J(a); gl 14, 15 idle (they stream ones and are ignored)
+__constant__ const signed char kFitX[16] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 4, 3, 3, 3, 3, 4, 4};
+__constant__ const signed char kFitY[16] = {0, 1, 2, 4, 1, 2, 4, 2, 4, 4, 0, 1, 2, 4, 4, 4};
+__constant__ const signed char kFitRow[16] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 0, 1, 2, 3, 0, 0};  // H: row a | J: a
+__constant__ const signed char kFitColI[16] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3, 0, 0, 0, 0, 0, 0}; // H: column b
 
 // Ordered double sum of this lane's accumulator over the padded lists (m8 = longest of the four, rounded up to 8).
 // Blocks of 8 whose residuals are in the Huber core for all four seeds take the plain path.  Otherwise every element
@@ -800,7 +804,8 @@ __constant__ const signed char kFitY[16] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3, 0, 1, 
 // all four seeds' residuals in the Huber core (the usual case after the first step): no masks, and the next block's
 // operands are fetched while this block's adds run -- a wave of this kernel has a SIMD almost to itself, so the LDS
 // latency is not hidden by other waves
-__device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const float *yc, int m8) {
+// (xs, ys: 1 = the operand advances with the element index, 0 = it is the shared block of ones)
+__device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const float *yc, int xs, int ys, int m8) {
     const float4 *x4 = reinterpret_cast<const float4 *>(xc), *y4 = reinterpret_cast<const float4 *>(yc);
     float4 xa = x4[0], xb = x4[1], ya = y4[0], yb = y4[1];
     double acc = 0.0;
@@ -808,7 +813,7 @@ __device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const fl
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int b = 8; b <= m8; b += 8) {
         const int nb = b < m8 ? b >> 2 : 0;
-        const float4 pxa = x4[nb], pxb = x4[nb + 1], pya = y4[nb], pyb = y4[nb + 1];
+        const float4 pxa = x4[nb * xs], pxb = x4[nb * xs + 1], pya = y4[nb * ys], pyb = y4[nb * ys + 1];
         acc += (double)(xa.x * ya.x); a1 += (double)(xa.y * ya.y); a2 += (double)(xa.z * ya.z); a3 += (double)(xa.w * ya.w);
         acc += (double)(xb.x * yb.x); a1 += (double)(xb.y * yb.y); a2 += (double)(xb.z * yb.z); a3 += (double)(xb.w * yb.w);
         xa = pxa; xb = pxb; ya = pya; yb = pyb;
@@ -817,7 +822,7 @@ __device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const fl
 #endif
     for (int b = 8; b <= m8; b += 8) {
         const int nb = b < m8 ? b >> 2 : 0; // (the last round re-reads block 0 and drops it)
-        const float4 pxa = x4[nb], pxb = x4[nb + 1], pya = y4[nb], pyb = y4[nb + 1];
+        const float4 pxa = x4[nb * xs], pxb = x4[nb * xs + 1], pya = y4[nb * ys], pyb = y4[nb * ys + 1];
         acc += (double)(xa.x * ya.x); acc += (double)(xa.y * ya.y); acc += (double)(xa.z * ya.z); acc += (double)(xa.w * ya.w);
         acc += (double)(xb.x * yb.x); acc += (double)(xb.y * yb.y); acc += (double)(xb.z * yb.z); acc += (double)(xb.w * yb.w);
         xa = pxa; xb = pxb; ya = pya; yb = pyb;
@@ -825,9 +830,9 @@ __device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const fl
     return 2.0 * acc;
 }
 
-__device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *yc, int m8, const unsigned long long noncore[4],
-                                                  bool is_j, double hr) {
-    if (__ballot((noncore[0] | noncore[1] | noncore[2] | noncore[3]) != 0) == 0) return fit_ordered_sum_core(xc, yc, m8);
+__device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *yc, int xs, int ys, int m8,
+                                                  const unsigned long long noncore[4], bool is_j, double hr) {
+    if (__ballot((noncore[0] | noncore[1] | noncore[2] | noncore[3]) != 0) == 0) return fit_ordered_sum_core(xc, yc, xs, ys, m8);
     double acc = 0.0;
     const double k_lane = is_j ? 0.5 * hr : 0.0;
 #pragma unroll
@@ -836,18 +841,18 @@ __device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *
         if (lim <= 0) break;
         for (int j = 0; j < lim; j += 8) { // 8 at a time: two operand columns, register budget
             const int b = k * 64 + j;
-            const float4 xa = *reinterpret_cast<const float4 *>(xc + b), xb = *reinterpret_cast<const float4 *>(xc + b + 4);
-            const float4 ya = *reinterpret_cast<const float4 *>(yc + b), yb = *reinterpret_cast<const float4 *>(yc + b + 4);
-            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            const float ys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            const float4 xa = *reinterpret_cast<const float4 *>(xc + b * xs), xb = *reinterpret_cast<const float4 *>(xc + b * xs + 4);
+            const float4 ya = *reinterpret_cast<const float4 *>(yc + b * ys), yb = *reinterpret_cast<const float4 *>(yc + b * ys + 4);
+            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
             const unsigned n8 = (unsigned)(noncore[k] >> j) & 0xffu; // this lane's seed
             if (__ballot(n8 != 0) == 0) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) acc += (double)(xs[q] * ys[q]);
+                for (int q = 0; q < 8; q++) acc += (double)(xv[q] * yv[q]);
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const double v = (double)(xs[q] * ys[q]);
+                    const double v = (double)(xv[q] * yv[q]);
                     const double scale = ((n8 >> q) & 1u) ? k_lane : 1.0;
                     acc += v * scale;
                 }
@@ -857,9 +862,10 @@ __device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *
     return 2.0 * acc;
 }
 
-__global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][kFitStride];
+    __shared__ __attribute__((aligned(16))) float s_ones[8];
     __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
     const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
     const int S = c->n_seed;
@@ -902,7 +908,8 @@ __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
     stamp(c, 4, s0, 1, lane);
 
     if (m_max > 0) {
-        // ---- lists into LDS: p columns from k_seed_points' hand-off, ones, zeroed residuals, all padded to m8
+        // ---- lists into LDS: p columns from k_seed_points' hand-off, zeroed residuals, all padded to m8
+        if (lane < 8) s_ones[lane] = 1.0f;
 #pragma unroll
         for (int q = 0; q < kFitSeeds; q++) {
             const float *pts = c->gn_pts + (int64_t)(s0 + q < S ? s0 + q : S - 1) * 3 * kGnCap;
@@ -918,10 +925,7 @@ __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
                     if (i4 + 3 >= mg[q]) v.w = 0.0f;
                     *reinterpret_cast<float4 *>(&s_col[q][col][i4]) = v;
                 }
-                const float4 one = make_float4(i4 < mg[q] ? 1.0f : 0.0f, i4 + 1 < mg[q] ? 1.0f : 0.0f, i4 + 2 < mg[q] ? 1.0f : 0.0f,
-                                               i4 + 3 < mg[q] ? 1.0f : 0.0f);
-                *reinterpret_cast<float4 *>(&s_col[q][3][i4]) = one;
-                *reinterpret_cast<float4 *>(&s_col[q][4][i4]) = make_float4(0, 0, 0, 0);
+                *reinterpret_cast<float4 *>(&s_col[q][3][i4]) = make_float4(0, 0, 0, 0);
             }
         }
         // per-lane rows of the tabled 4x4 inverse (dsm_math.h, kInv4)
@@ -932,9 +936,10 @@ __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
 #pragma unroll
         for (int q = 0; q < 7; q++) oe[q] = kInv4.out[gl][q];
         double *SA = s_solver[g], *SD = SA + 16, *SO = SA + 28, *SJ = SA + 44, *SU = SA + 48;
-        const int xs = kFitX[gl], ys = kFitY[gl];
-        const bool is_j = xs == 4;
-        const float *xc = s_col[g][xs], *yc = s_col[g][ys];
+        const int xcol = kFitX[gl], ycol = kFitY[gl], h_row = kFitRow[gl], h_col = kFitColI[gl];
+        const bool is_j = gl >= 10 && gl < 14;
+        const float *xc = xcol == 4 ? s_ones : s_col[g][xcol], *yc = ycol == 4 ? s_ones : s_col[g][ycol];
+        const int xs = xcol == 4 ? 0 : 1, ys = ycol == 4 ? 0 : 1;
         wave_lds_sync();
         // this lane's points of every list (element k*64+lane of seed q), for the residuals
         float pq[kFitSeeds][4][3];
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
                 const float r = pq[q][0][0] * pn[q][0] + pq[q][0][1] * pn[q][1] + pq[q][0][2] * pn[q][2] + pn[q][3];
                 const int cls = huber_class(r, hr);
                 // the residual column carries the tail sign for outliers (see fit_ordered_sum)
-                if (valid) s_col[q][4][lane] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
+                if (valid) s_col[q][3][lane] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
                 const unsigned long long mask = __ballot(valid && cls != 0);
                 if (g == q) noncore[0] = mask;
             }
@@ -981,14 +986,14 @@ __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
                         const bool valid = i < mg[q];
                         const float r = pq[q][k][0] * pn[q][0] + pq[q][k][1] * pn[q][1] + pq[q][k][2] * pn[q][2] + pn[q][3];
                         const int cls = huber_class(r, hr);
-                        if (valid) s_col[q][4][i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
+                        if (valid) s_col[q][3][i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
                         const unsigned long long mask = __ballot(valid && cls != 0);
                         if (g == q) noncore[k] = mask;
                     }
                 }
             }
             wave_lds_sync();
-            const double acc = fit_ordered_sum(xc, yc, m8, noncore, is_j, hr);
+            const double acc = fit_ordered_sum(xc, yc, xs, ys, m8, noncore, is_j, hr);
             // The Hessian sums read nothing but the points and which elements are in the Huber core: while the class
             // masks of all four seeds stay what they were when H was last summed (from the second step on they are
             // normally all-core), H, its damped inverse and the determinant are bit for bit the same, and the
@@ -1003,9 +1008,12 @@ __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx) {
                 for (int k = 0; k < 4; k++) h_masks[k] = noncore[k];
                 // damped solve, FF.cpp:172-180: one lane per 2x2 determinant, per adjugate entry, per row -- per seed
                 if (gl < 10) {
-                    const double v = xs == ys ? acc + 5 : acc; // +5 on the diagonal
-                    SA[ys * 4 + xs] = v;
-                    SA[xs * 4 + ys] = v;
+                    // H(3,3) += 2 per core element (FF.cpp:150): an integer, no sum needed
+                    const int n_core = m - (__popcll(noncore[0]) + __popcll(noncore[1]) + __popcll(noncore[2]) + __popcll(noncore[3]));
+                    const double hv = gl == 9 ? 2.0 * (double)n_core : acc;
+                    const double v = h_row == h_col ? hv + 5 : hv; // +5 on the diagonal
+                    SA[h_col * 4 + h_row] = v;
+                    SA[h_row * 4 + h_col] = v;
                 }
                 wave_lds_sync();
                 if (gl < 12) SD[gl] = SA[d2[0]] * SA[d2[1]] - SA[d2[2]] * SA[d2[3]];
@@ -1103,8 +1111,8 @@ __device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s
     }
 }
 
-__global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ __attribute__((aligned(16))) float s_rec[256 * kRecDw];
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
@@ -1434,8 +1442,8 @@ __device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c,
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, int with_compaction) {
-    const DeviceCtx *__restrict__ c = &ctx;
+template <bool BATCH> __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int with_compaction) {
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
     __shared__ int s_idx[kTailFastSeeds], s_refill[kTailFastSeeds];
@@ -1653,14 +1661,22 @@ const char *const kStageNames[kNumStages] = {
     "assign_2",   "resolve_2", "update_seeds_2", "commit_seeds_2", "seed_points", "seed_fit", "fuse_surfels", "frame_tail",
 };
 
+// d_batch != nullptr: the kernels take their context from d_batch[blockIdx.z], z < n_batch (handles of equal geometry
+// advancing in lockstep: one launch per kernel for all of them); hc is then any one of them (grid sizes).
 hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
-                        hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi) {
+                        hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi, const DeviceCtx *d_batch, int n_batch) {
     int stage = 0;
     hipError_t err = hipSuccess;
+    const bool batched = d_batch != nullptr;
+    const unsigned nz = batched ? (unsigned)n_batch : 1u;
 // launches only the stages whose index (position in kStageNames) lies in [stage_lo, stage_hi]
-#define hipLaunchStage(...)                                   \
-    do {                                                      \
-        if (stage - 1 >= stage_lo && stage - 1 <= stage_hi) hipLaunchKernelGGL(__VA_ARGS__); \
+#define hipLaunchStage(kernel_single, kernel_batch, grid, block, ...)                                        \
+    do {                                                                                                     \
+        if (stage - 1 >= stage_lo && stage - 1 <= stage_hi) {                                                \
+            const dim3 g_((grid).x, (grid).y, nz);                                                           \
+            if (batched) hipLaunchKernelGGL(kernel_batch, g_, block, 0, st, hc, d_batch, ##__VA_ARGS__);   \
+            else hipLaunchKernelGGL(kernel_single, g_, block, 0, st, hc, d_batch, ##__VA_ARGS__);          \
+        }                                                                                                    \
     } while (0)
 #define DSM_MARK()                                                                      \
     do {                                                                                \
@@ -1682,43 +1698,43 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     (void)g_seed_tile;
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
-    hipLaunchStage(k_init_seeds, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256), 0, st, hc);
+    hipLaunchStage(k_init_seeds<false>, k_init_seeds<true>, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256));
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
-            hipLaunchStage(k_assign<true>, g_tile, dim3(256), 0, st, hc, sweep);
+            hipLaunchStage((k_assign<true, false>), (k_assign<true, true>), g_tile, dim3(256), sweep);
             DSM_MARK();
 #if DSM_TILED_UPDATE
-            hipLaunchStage(k_update_seeds_tiled<false>, g_seed_tile, dim3(256), 0, st, hc, sweep);
+            hipLaunchStage((k_update_seeds_tiled<false, false>), (k_update_seeds_tiled<false, true>), g_seed_tile, dim3(256), sweep);
 #else
-            hipLaunchStage(k_update_seeds<false>, g_seed_wave, dim3(256), 0, st, hc, sweep);
+            hipLaunchStage((k_update_seeds<false, false>), (k_update_seeds<false, true>), g_seed_wave, dim3(256), sweep);
 #endif
             DSM_MARK();
         } else {
-            hipLaunchStage(k_assign<false>, g_tile, dim3(256), 0, st, hc, sweep);
+            hipLaunchStage((k_assign<false, false>), (k_assign<false, true>), g_tile, dim3(256), sweep);
             DSM_MARK();
-            hipLaunchStage(k_resolve, dim3(1), dim3(256), 0, st, hc, sweep);
+            hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
             DSM_MARK();
 #if DSM_TILED_UPDATE
-            hipLaunchStage(k_update_seeds_tiled<true>, g_seed_tile, dim3(256), 0, st, hc, sweep);
+            hipLaunchStage((k_update_seeds_tiled<true, false>), (k_update_seeds_tiled<true, true>), g_seed_tile, dim3(256), sweep);
 #else
-            hipLaunchStage(k_update_seeds<true>, g_seed_wave, dim3(256), 0, st, hc, sweep);
+            hipLaunchStage((k_update_seeds<true, false>), (k_update_seeds<true, true>), g_seed_wave, dim3(256), sweep);
 #endif
             DSM_MARK();
         }
-        hipLaunchStage(k_commit_seeds, g_seed_thr, dim3(256), 0, st, hc, sweep);
+        hipLaunchStage(k_commit_seeds<false>, k_commit_seeds<true>, g_seed_thr, dim3(256), sweep);
         DSM_MARK();
     }
-    hipLaunchStage(k_seed_points, g_seed_wave, dim3(256), 0, st, hc);
+    hipLaunchStage(k_seed_points<false>, k_seed_points<true>, g_seed_wave, dim3(256));
     DSM_MARK();
-    hipLaunchStage(k_seed_fit, dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64), 0, st, hc);
+    hipLaunchStage(k_seed_fit<false>, k_seed_fit<true>, dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
     DSM_MARK();
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;
     if (fuse_blocks > 2048) fuse_blocks = 2048;
-    hipLaunchStage(k_fuse_surfels, dim3(fuse_blocks), dim3(256), 0, st, hc);
+    hipLaunchStage(k_fuse_surfels<false>, k_fuse_surfels<true>, dim3(fuse_blocks), dim3(256));
     DSM_MARK();
-    hipLaunchStage(k_frame_tail, dim3(1), dim3(1024), 0, st, hc, with_compaction ? 1 : 0);
+    hipLaunchStage(k_frame_tail<false>, k_frame_tail<true>, dim3(1), dim3(1024), with_compaction ? 1 : 0);
     DSM_MARK();
     if (ev) { // empty interval: what a pair of event records costs by itself
         err = hipEventRecord(ev[stage], st);

@@ -200,6 +200,22 @@ int dsm_last_new_count(dsm_handle *h, int32_t *n_new);
 /* the handle's hipStream_t, for event timing by the caller */
 int dsm_stream(dsm_handle *h, void **hip_stream);
 
+/* ---- batches: handles of equal image size on one device, each with its own map and frames (independent subsequences,
+ * surfel_map.cpp has no counterpart: it fuses one frame at a time), advancing in LOCKSTEP: every kernel of a frame is
+ * launched once for the whole batch (grid z = handle).  Launch overheads, cold caches and the slowest waves of a kernel
+ * are shared by all subsequences instead of paid by each: this is what bench.py's headline replays.  Handles must have
+ * pipeline_depth 1 and a resident map; they stay usable on their own between batch calls (every handle's stream is
+ * ordered behind the batch). ---- */
+typedef struct dsm_batch dsm_batch;
+int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out);
+void dsm_batch_destroy(dsm_batch *b);
+const char *dsm_batch_last_error(const dsm_batch *b);
+/* enqueue n_frames frames for every handle: frame i of handle j uses slots[j * n_frames + i], ref_idx[...], and
+ * poses16[(j * n_frames + i) * 16 ..] */
+int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx, const float *poses16);
+/* wait for everything enqueued and report the first handle's error, if any */
+int dsm_batch_synchronize(dsm_batch *b);
+
 /* ---- parity taps (state after the last completed frame; synchronise) ------------------- */
 int dsm_get_labels(dsm_handle *h, int32_t *out /* height*width */);
 int dsm_get_seeds(dsm_handle *h, dsm_seed *out /* (width/8)*(height/8) */);
@@ -238,6 +254,10 @@ typedef struct dsm_stage_times {
  * accumulate per-stage durations */
 int dsm_replay_timed(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx,
                      const float *poses16, dsm_stage_times *out);
+/* the same for a batch (arguments as dsm_batch_replay_enqueue): durations are those of the batched launches; `frames`,
+ * sum_new and sum_local count handle-frames */
+int dsm_batch_replay_timed(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx,
+                           const float *poses16, dsm_stage_times *out);
 
 #ifdef __cplusplus
 }

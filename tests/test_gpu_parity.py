@@ -257,6 +257,49 @@ def test_batched_replay_matches_stepwise(mods):
     _compare_frame("after 24 frames", ff, orc, ff.map_download(), lo.astype(api.SURFEL_DTYPE))
 
 
+def test_batched_lockstep_replay(mods):
+    """dsm_batch_*: five handles with five different scenes advance in lockstep, every kernel launched once for all of
+    them (grid z = handle); each subsequence's map equals the oracle's for its own scene, and a handle used alone
+    afterwards continues correctly."""
+    api, synth, ob = mods
+    cam = synth.VGA_DRIVE
+    n, B = 14, 5
+    scenes = [synth.Scene(seed=200 + 7 * b, n_boxes=6 + b) for b in range(B)]
+    handles, plans, frames = [], [], []
+    for b in range(B):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 18, pipeline_depth=1)
+        fr = list(synth.sequence(cam, scenes[b], n))
+        for t, img, dep, pose, ref in fr:
+            ff.frame_upload(t, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        plans.append(api.FusionFunctions.pack_replay([f[0] for f in fr], [f[4] for f in fr], np.stack([f[3] for f in fr])))
+        handles.append(ff)
+        frames.append(fr)
+    batch = api.Batch(handles)
+    first = 9
+    s, r, p, _ = api.Batch.pack([(pl[0][:first], pl[1][:first], pl[2][:first]) for pl in plans])
+    batch.replay_enqueue(s, r, p, first)
+    s, r, p, _ = api.Batch.pack([(pl[0][first:n - 1], pl[1][first:n - 1], pl[2][first:n - 1]) for pl in plans])
+    batch.replay_enqueue(s, r, p, n - 1 - first)
+    batch.synchronize()
+    for b in range(B):
+        orc = ob.PortOracle(cam)
+        lo = np.zeros(0, ob.SURFEL_DTYPE)
+        for t, img, dep, pose, ref in frames[b][:n - 1]:
+            lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+        _compare_frame(f"batched subsequence {b}", handles[b], orc, handles[b].map_download(), lo.astype(api.SURFEL_DTYPE))
+        # the handle on its own again: the last frame through its own stream
+        t, img, dep, pose, ref = frames[b][n - 1]
+        handles[b].fuse_frame_resident(t, ref, pose)
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+        _compare_frame(f"subsequence {b} alone after the batch", handles[b], orc, handles[b].map_download(), lo.astype(api.SURFEL_DTYPE))
+    with pytest.raises(api.DsmError):  # handles whose parameter rings are out of step cannot be batched
+        api.Batch([handles[0], api.FusionFunctions.from_camera(cam, pipeline_depth=1)])
+    batch.close()
+    for ff in handles:
+        ff.close()
+
+
 def test_rgbd_constant_set(mods):
     """BASELINE config 4 shape: 640x480 with the RGB-D constants of fusion_functions.h:17-21."""
     api, synth, ob = mods
