@@ -63,11 +63,11 @@ KERNEL_OF_STAGE = {
 }
 
 
-def pmc_traffic(stage):
+def pmc_traffic(stage, name="r02_pmc_traffic.json"):
     """HBM-side bytes per launch of `stage` from the committed rocprofv3 --pmc passes of this round (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, tools/gpu_pmc.sh; the JSON records them with the calibration used).
     Counters cannot be read from inside the run; None when no measurement is on file."""
-    for name in ("r02_pmc_traffic.json",):
+    for name in (name,):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -153,14 +153,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSM_BENCH_STREAMS", "8")),
-                    help="independent subsequences (handles/streams) per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSM_BENCH_STREAMS", "0")),
+                    help="independent subsequences (handles) per GPU; 0 = 32 in batched mode, 8 in streams mode")
     ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSM_BENCH_FRAMES_PER_STEP", "32")),
                     help="frames every subsequence advances per step")
     ap.add_argument("--mode", choices=("batched", "streams"), default=os.environ.get("DSM_BENCH_MODE", "batched"),
                     help="batched: the B subsequences advance in lockstep, one launch per kernel for all of them (dsm_batch_*); "
                          "streams: B handles on B streams, the hardware queues overlap their kernels (round 1's mode)")
-    ap.add_argument("--batches", type=int, default=int(os.environ.get("DSM_BENCH_BATCHES", "1")),
+    ap.add_argument("--batches", type=int, default=int(os.environ.get("DSM_BENCH_BATCHES", "4")),
                     help="batched mode: split the B subsequences into this many batches, each on its own stream")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("DSM_BENCH_HOST_THREADS", "4")),
                     help="host threads enqueueing graph replays (each drives streams/threads handles)")
@@ -174,7 +174,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    B, K, W, F = args.streams, args.steps, args.warmup, args.frames_per_step
+    B, K, W, F = args.streams or (32 if args.mode == "batched" else 8), args.steps, args.warmup, args.frames_per_step
     period = 50
     extras = rank == 0 and world == 1 and not args.no_dropin
 
@@ -183,8 +183,13 @@ def main():
     cam = synth.KITTI_1226
     n_seed = (cam.width // 8) * (cam.height // 8)
     n_pix = cam.width * cam.height
-    scenes = [synth.Scene(seed=12345 + 1000 * rank + 17 * b, frames_per_period=period) for b in range(B)]
-    jobs = [(cam, scenes[b], i) for b in range(B) for i in range(period)]
+    # up to 16 different scenes per rank; subsequences beyond that replay a scene from half a period further on (other
+    # images at any time, another map)
+    n_scene = min(B, 16)
+    scenes = [synth.Scene(seed=12345 + 1000 * rank + 17 * b, frames_per_period=period) for b in range(n_scene)]
+    scene_of = [b % n_scene for b in range(B)]
+    phase_of = [(b // n_scene) * (period // 2) % period for b in range(B)]
+    jobs = [(cam, scenes[b], i) for b in range(n_scene) for i in range(period)]
     cam_v, scene_v = synth.VGA_RGBD, synth.Scene(seed=5, scale=0.12, step=0.05, frames_per_period=30)
     cam_h, scene_h = synth.FULLHD, synth.Scene(seed=12345, frames_per_period=10)
     if extras:
@@ -193,9 +198,9 @@ def main():
     t_r = time.perf_counter()
     frames_all = synth.render_many(jobs, workers)
     render_s = time.perf_counter() - t_r
-    rendered = [frames_all[b * period:(b + 1) * period] for b in range(B)]
-    frames_v = frames_all[B * period:B * period + 30] if extras else []
-    frames_h = frames_all[B * period + 30:B * period + 40] if extras else []
+    rendered = [frames_all[b * period:(b + 1) * period] for b in range(n_scene)]
+    frames_v = frames_all[n_scene * period:n_scene * period + 30] if extras else []
+    frames_h = frames_all[n_scene * period + 30:n_scene * period + 40] if extras else []
 
     import torch
     from densesurfelmapping_amd import api
@@ -218,18 +223,22 @@ def main():
     total = (W + K) * F
     lo_t, hi_t = W * F, total  # frame indices of the timed region, per subsequence
     capacity = 1 << 21
-    handles, plans = [], []
-    for b in range(B):
-        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity,
-                                             pipeline_depth=args.pipeline_depth or 1)  # B subsequences already fill the queues
-        for i, (img, dep) in enumerate(rendered[b]):
+    def make_handle(b, **kw):
+        """Subsequence b: its scene's period of frames resident in HBM, an empty map, and its replay plan."""
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity, **kw)
+        for i, (img, dep) in enumerate(rendered[scene_of[b]]):
             ff.frame_upload(i, img, dep)
         ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
-        slots = [t % period for t in range(total)]
+        return ff
+
+    def make_plan(b):
+        slots = [(t + phase_of[b]) % period for t in range(total)]
         refs = [t // 5 for t in range(total)]
-        poses = np.stack([scenes[b].pose(t) for t in range(total)])
-        plans.append(api.FusionFunctions.pack_replay(slots, refs, poses))
-        handles.append(ff)
+        poses = np.stack([scenes[scene_of[b]].pose(t + phase_of[b]) for t in range(total)])
+        return api.FusionFunctions.pack_replay(slots, refs, poses)
+
+    handles = [make_handle(b, pipeline_depth=args.pipeline_depth or 1) for b in range(B)]  # B subsequences already fill the queues
+    plans = [make_plan(b) for b in range(B)]
 
     # Enqueue: every handle has its own stream; T host threads each drive B/T handles (the C ABI is
     # thread-safe per handle and ctypes drops the GIL during the call), chunk by chunk so that all
@@ -323,7 +332,8 @@ def main():
                    "timed_frame_indices": [lo_t, hi_t - 1], "host_enqueue_threads": n_thr,
                    "pipeline_depth": args.pipeline_depth or 1,
                    "host_enqueue_seconds": round(enqueue_s[0], 4), "timed_seconds": round(dt, 4), "scene_period_frames": period,
-                   "scenes": "one synthetic scene per subsequence (seed 12345 + 1000*rank + 17*b)",
+                   "scenes": f"{n_scene} synthetic scenes per rank (seed 12345 + 1000*rank + 17*b); subsequences beyond {n_scene} replay a "
+                             "scene from half a period further on",
                    "host_render_seconds": round(render_s, 1),
                    "mean_live_surfels": round(m_avg), "final_surfels_all_ranks": merged_total,
                    "parallelism": f"{world} GPU x {B} independent subsequences, all-gather of final cloud only"},
@@ -334,10 +344,7 @@ def main():
         # per-kernel durations, measured live with HIP events on the handle's own stream (eager replay of frames of
         # the timed region of subsequence 0 on a fresh handle; a long delay kernel in front of each frame keeps the
         # host launch latency out of the intervals).  K and M of B_alg are measured on the same frames.
-        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity)
-        for i, (img, dep) in enumerate(rendered[0]):
-            ff.frame_upload(i, img, dep)
-        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        ff = make_handle(0)
         s, r, p = plans[0]
         ff.replay_enqueue(s[:lo_t], r[:lo_t], p[:lo_t])
         ff.synchronize()
@@ -377,14 +384,51 @@ def main():
         b_alg_t = 9 * n_pix + 60 * n_seed + 88 * mt + 44 * k_avg
         out["kernel_time_weighted_hbm_frac"] = round(b_alg_t / ksum / 1e9 / HBM_PEAK_GBS, 5)
         ff.close()
+        if args.mode == "batched":
+            # ... and of the launches the timed region actually makes: one batch of the subsequences, every kernel
+            # launched once for all of them.  The roofline is that of these launches (bytes of all subsequences of the
+            # batch / launch duration).
+            nb = len(groups_b[0])
+            hs = [make_handle(b, pipeline_depth=1) for b in groups_b[0]]
+            bt = api.Batch(hs)
+            sb, rb, pb, nn = api.Batch.pack([(plans[b][0][:lo_t], plans[b][1][:lo_t], plans[b][2][:lo_t]) for b in groups_b[0]])
+            bt.replay_enqueue(sb, rb, pb, nn)
+            bt.synchronize()
+            n_evb = min(hi_t - lo_t, 48)
+            sb, rb, pb, nn = api.Batch.pack([(plans[b][0][lo_t:lo_t + n_evb], plans[b][1][lo_t:lo_t + n_evb], plans[b][2][lo_t:lo_t + n_evb])
+                                             for b in groups_b[0]])
+            stb, nfb = bt.replay_timed(sb, rb, pb, nn)
+            mtb, kb = bt.timed_mean_local, bt.timed_mean_new
+            ovb = bt.event_overhead_ms * 1e3
+            perb = {k: max(v[0] / max(v[1], 1) * 1e3 - ovb, 0.0) for k, v in stb.items()}  # us per batched launch
+            dom_usb = float(np.mean([perb[x] for x in dom_stages]))
+            algb = nb * float(np.mean([stage_alg_bytes(x, n_pix, n_seed, mtb, kb) for x in dom_stages]))
+            achb = algb / (dom_usb * 1e-6) / 1e9
+            # (batched instantiations carry a second template argument: k_update_seeds<true> -> k_update_seeds<true, true>)
+            fn_b = dom_fn[:-1] + ", true>" if dom_fn.endswith(">") else dom_fn + "<true>"
+            traffic_b, traffic_src_b = pmc_traffic(fn_b, "r02_pmc_traffic_batched.json") if nb == 8 else (None, None)
+            out["roofline_single_launch"] = out["roofline"]
+            out["roofline"] = {"bound": "hbm", "kernel": dom_fn, "launches_per_frame": len(dom_stages), "subsequences_per_launch": nb,
+                               "achieved": round(achb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achb / HBM_PEAK_GBS, 5),
+                               "traffic": traffic_b,
+                               "traffic_source": (f"profiles/{traffic_src_b} (rocprofv3 --pmc of launches batched over 8 subsequences, separate passes)"
+                                                  if traffic_src_b else None),
+                               "event_overhead_us": round(ovb, 2), "alg_bytes_per_launch": int(algb), "avg_launch_us": round(dom_usb, 2),
+                               "frames_timed": int(nfb), "mean_live_surfels": round(mtb), "mean_new_surfels": round(kb, 1),
+                               "note": "the timed region launches every kernel once per batch of subsequences; roofline_single_launch is the "
+                                       "same kernel launched for one subsequence"}
+            out["batched_kernel_us"] = {k: round(v, 2) for k, v in perb.items()}
+            out["batched_kernel_hbm_frac"] = {k: round(nb * stage_alg_bytes(k, n_pix, n_seed, mtb, kb) / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                                              for k, v in perb.items() if v > 0}
+            out["batched_frame_kernel_sum_us_per_frame"] = round(sum(perb.values()) / nb, 1)
+            bt.close()
+            for h_ in hs:
+                h_.close()
 
     if extras:
         # ONE sequence (BASELINE configs[1] as the reference would replay it): frames are strictly ordered, but
         # only fuse + tail need the map -- the superpixel stages of up to 8 frames run ahead on their own streams
-        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity, pipeline_depth=8)
-        for i, (img, dep) in enumerate(rendered[0]):
-            ff.frame_upload(i, img, dep)
-        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        ff = make_handle(0, pipeline_depth=8)
         s1, r1, p1 = plans[0]
         ff.replay_enqueue(s1[:lo_t], r1[:lo_t], p1[:lo_t])
         ff.synchronize()
@@ -395,7 +439,6 @@ def main():
                                   "note": "one subsequence, one handle: superpixel stages of 8 consecutive frames in flight, "
                                           "fuse + compaction strictly in frame order; same results as the serial order"}
         ff.close()
-
     if extras:
         # the synchronous drop-in call (host buffers in and out over PCIe every frame), for DESIGN.md;
         # never the headline value
@@ -415,7 +458,6 @@ def main():
                                                 "vector is compared with what the previous call returned (and uploaded only if the caller "
                                                 "changed it), the whole map comes back"}
         ff.close()
-
     if extras:
         # BASELINE configs[4]: 1920x1080 depth stream against >= 2 M live surfels, and the loop-closure deformation
         # (surfel_map.cpp:750-789).  The big map is the map of a short 1080p replay replicated
@@ -486,7 +528,6 @@ def main():
                               "hbm_frac": round(88 * n_w / us_w8 / 1e3 / HBM_PEAK_GBS, 4),
                               "timing": "HIP events around 30 back-to-back dsm_map_warp calls (704 MB moved per call)"}
         ff.close()
-
     if extras:
         # BASELINE configs[3]: live callback, 640x480 RGB-D constants, one frame at a time: host frame in
         # (H2D), resident map, one hipGraph replay, wait -- the latency the 30 Hz node would see per frame
@@ -506,7 +547,6 @@ def main():
                                         "map_surfels": ff.map_size(),
                                         "note": "per frame: pageable host image+depth H2D, fuse (one graph replay), stream sync; RGB-D constant set"}
         ff.close()
-
     if extras:
         # the whole node through its message callbacks (stamp matching, pose graph, active /
         # inactive sets in HBM, loop closure at the start of the second lap), host-inclusive: every frame is copied into

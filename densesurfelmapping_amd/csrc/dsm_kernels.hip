@@ -149,6 +149,24 @@ __device__ __forceinline__ int seed_of_block(int b, int wv, int gw, int gh) {
     return (gx < gw && gy < gh) ? gy * gw + gx : -1;
 }
 
+// Launches batched over handles (grid z = handle): which handle and which block of it this workgroup takes.
+// Workgroups go to the XCDs round-robin in dispatch order (x fastest, then z), so with the handle taken from the
+// low bits of the dispatch index a batch of eight puts each handle on ONE XCD: the overlapping windows of a frame
+// then meet in one L2 instead of being fetched over the fabric by all eight.
+#ifndef DSM_BATCH_XCD
+#define DSM_BATCH_XCD 1
+#endif
+struct BlockOf { int z, x, y; };
+template <bool BATCH> __device__ __forceinline__ BlockOf block_of() {
+    if (!BATCH) return {0, (int)blockIdx.x, (int)blockIdx.y};
+#if DSM_BATCH_XCD
+    const unsigned l = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), r = l / gridDim.z;
+    return {(int)(l % gridDim.z), (int)(r % gridDim.x), (int)(r / gridDim.x)};
+#else
+    return {(int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y};
+#endif
+}
+
 __device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur->p; }
 __device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return c->cur->img; }
 __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur->dep; }
@@ -161,17 +179,18 @@ __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const Fr
 // per seed read from L2); the first hit is the lowest lane with one: one ballot per wave.
 constexpr int kInitLanes = 16, kInitSeedsPerBlock = 256 / kInitLanes;
 template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     const int tid = threadIdx.x, lane = lane_id();
     const int r = tid & (kInitLanes - 1);
-    const int s = blockIdx.x * kInitSeedsPerBlock + tid / kInitLanes;
-    if (blockIdx.x == 0 && tid < kSweeps * kWorkers) c->first_empty[tid] = kIntMax;
-    if (blockIdx.x == 0 && tid == 0) c->work_count[0] = 0;
+    const int s = blk.x * kInitSeedsPerBlock + tid / kInitLanes;
+    if (blk.x == 0 && tid < kSweeps * kWorkers) c->first_empty[tid] = kIntMax;
+    if (blk.x == 0 && tid == 0) c->work_count[0] = 0;
     // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
     const FrameParams &fp = c->params[(unsigned)(c->cursor[0] * c->cursor_mul + c->cursor_add) % (unsigned)c->n_params];
     const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
     const float *dep = c->depth_base + (int64_t)fp.slot * c->slot_elems;
-    if (blockIdx.x == 0 && tid < 64) {
+    if (blk.x == 0 && tid < 64) {
         FrameCur *wc = c->cur;
         const int t = tid;
         if (t < 16) wc->p.pose[t] = fp.pose[t];
@@ -257,7 +276,8 @@ __device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
 }
 
 template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
     const FrameParams &fp = frame_params(c);
@@ -265,7 +285,7 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
     const float *dep = frame_depth(c, fp);
     const int32_t *label_in = ((sweep - 1) & 1) ? c->label_alt : c->label; // sweep >= 1
     const int w = c->w, h = c->h, pitch = c->pitch, gw = c->gw, gh = c->gh;
-    const int bx = blockIdx.x * kTileW, by = blockIdx.y * kTileH;
+    const int bx = blk.x * kTileW, by = blk.y * kTileH;
     const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
     const int tid = threadIdx.x;
     if (tid < kTileCellsX * kTileCellsY) {
@@ -321,7 +341,8 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
 // "last block done" ticket costs a device-scope release per workgroup -- an L2 write-back on this
 // multi-XCD part -- and was 10x slower than the extra launch.)
 template <bool BATCH> __global__ __launch_bounds__(256) void k_resolve(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     resolve_worklist(c, ((sweep - 1) & 1) ? c->label_alt : c->label);
 }
 
@@ -435,11 +456,12 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
 }
 
 template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
+    const int s = seed_of_block(blk.x, wv, c->gw, c->gh);
     if (s < 0) return;
     stamp(c, sweep, s, 0, lane);
     const FrameParams &fp = frame_params(c);
@@ -600,8 +622,9 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
 
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
 template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    const int s = blk.x * 256 + threadIdx.x;
     if (s == 0) c->work_count[0] = 0;
     if (s >= c->n_seed) return;
     if (c->tmin[s] == kIntMax) return;
@@ -643,10 +666,11 @@ constexpr int kCols = 6; // LDS columns per wave of k_seed_points, reused across
 constexpr int kColStride = kWin * kWin + 4;
 
 template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = seed_of_block(blockIdx.x, wv, c->gw, c->gh);
+    const int s = seed_of_block(blk.x, wv, c->gw, c->gh);
     if (s < 0) return;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
@@ -863,14 +887,15 @@ __device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *
 }
 
 template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][kFitStride];
     __shared__ __attribute__((aligned(16))) float s_ones[8];
     __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
     const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
     const int S = c->n_seed;
     const int n_groups = (S + kFitSeeds - 1) / kFitSeeds;
-    const int s0 = (n_groups - 1 - (int)blockIdx.x) * kFitSeeds; // bottom rows (long lists) first, see seed_of_block
+    const int s0 = (n_groups - 1 - blk.x) * kFitSeeds; // bottom rows (long lists) first, see seed_of_block
     const int s = s0 + g;
     const bool live = s < S;
     stamp(c, 4, s0, 0, lane);
@@ -1112,7 +1137,8 @@ __device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s
 }
 
 template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     __shared__ __attribute__((aligned(16))) float s_rec[256 * kRecDw];
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
@@ -1123,7 +1149,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
     fc.baseline = c->baseline; fc.disp_err = c->disp_err; fc.min_tol = c->min_tol;
     fc.w = c->w; fc.h = c->h;
     const int ref_idx = fp.ref_idx;
-    for (int base = blockIdx.x * 256; base < M; base += gridDim.x * 256) {
+    for (int base = blk.x * 256; base < M; base += gridDim.x * 256) {
         const int cnt = M - base < 256 ? M - base : 256;
         records_to_lds(s_rec, c->local + base, cnt, tid);
         __syncthreads();
@@ -1443,7 +1469,8 @@ __device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c,
 }
 
 template <bool BATCH> __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int with_compaction) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
     __shared__ int s_idx[kTailFastSeeds], s_refill[kTailFastSeeds];

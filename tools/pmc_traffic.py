@@ -38,11 +38,16 @@ def main():
     fetch = {short(k): v for k, v in per_kernel(fetch_dir, "FETCH_SIZE").items()}
     write = {short(k): v for k, v in per_kernel(write_dir, "WRITE_SIZE").items()}
     n = W * H
-    cal_f = (5 * n / 1024.0) / fetch["k_assign<true>"]
-    cal_w = (4 * n / 1024.0) / write["k_assign<true>"]
+    # (launches batched over several subsequences: the calibration kernel's known bytes scale with the batch)
+    nb = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    cal_name = "k_assign<true, true>" if nb > 1 else ("k_assign<true, false>" if "k_assign<true, false>" in fetch else "k_assign<true>")
+    n *= nb
+    cal_f = (5 * n / 1024.0) / fetch[cal_name]
+    cal_w = (4 * n / 1024.0) / write[cal_name]
     out = {"source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `{cmd}` (tools/gpu_pmc.sh), 1226x370",
            "units": "FETCH_SIZE / WRITE_SIZE are reported in KB",
-           "calibration": {"kernel": "k_assign<true>", "known_read_bytes": 5 * n, "known_write_bytes": 4 * n,
+           "subsequences_per_launch": nb,
+           "calibration": {"kernel": cal_name, "known_read_bytes": 5 * n, "known_write_bytes": 4 * n,
                            "fetch_factor_found": round(cal_f, 3), "write_factor_found": round(cal_w, 3),
                            "applied": "FETCH_SIZE x fetch_factor_found; WRITE_SIZE as reported when its factor is within 5 % of 1"},
            "kernels": {}}
