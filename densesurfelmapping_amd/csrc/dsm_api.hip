@@ -698,9 +698,14 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.spawn_ok, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.fused_flag, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_idx, (size_t)c.n_seed));
-        int32_t *ps = nullptr; // work_count, cursor, assign_done
+        int32_t *ps = nullptr; // work_count, cursor, assign_done, fit_big_count
         CREATE_TRY(dev_alloc(h, &ps, 64));
-        q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16;
+        q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16; q.fit_big_count = ps + 24;
+        q.fit_small_cap = kFitSmallCap;
+        if (const char *e = getenv("DSM_FIT_SMALL_CAP")) {
+            const int v = atoi(e);
+            if (v >= 0 && v < kFitSmallCap) q.fit_small_cap = v;
+        }
         CREATE_TRY(dev_alloc(h, &q.cur, 1));
         if (const char *e = getenv("DSM_WAVE_STAMPS"))
             if (e[0] == '1') CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));

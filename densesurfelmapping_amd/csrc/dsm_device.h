@@ -38,6 +38,7 @@ struct GnHeader {
     float far2;        // squared superpixel radius (FF.cpp:820-824)
 };
 constexpr int kGnCap = 232;
+constexpr int kFitSmallCap = 120; // longest list the short-column tier of k_seed_fit takes (batched launches)
 
 // Everything a kernel needs.  Passed to every kernel BY VALUE (kernel-argument segment): the pointers and
 // sizes never change after dsm_create, so a captured graph stays valid, and a kernel reaches its data
@@ -69,6 +70,8 @@ struct DeviceCtx {
     int32_t *first_empty; // [kSweeps][kWorkers] first unstable seed without pixels, per worker chunk
     int32_t *worklist;    // pixel keys whose old and new seeds were both stable at sweep start
     int32_t *work_count;
+    int32_t fit_small_cap;  // kFitSmallCap, or less (DSM_FIT_SMALL_CAP: lets a test push ordinary groups through the other tier)
+    int32_t *fit_big_count; // groups of seeds queued in `worklist` for the full-length tier of k_seed_fit (batched launches)
     GnHeader *gn_hdr; // [S]
     float *gn_pts;    // [S][3][kGnCap]
     dsm_seed *seeds; // [S] final seed table, reference layout

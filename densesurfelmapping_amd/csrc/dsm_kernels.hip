@@ -185,7 +185,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
     const int r = tid & (kInitLanes - 1);
     const int s = blk.x * kInitSeedsPerBlock + tid / kInitLanes;
     if (blk.x == 0 && tid < kSweeps * kWorkers) c->first_empty[tid] = kIntMax;
-    if (blk.x == 0 && tid == 0) c->work_count[0] = 0;
+    if (blk.x == 0 && tid == 0) c->work_count[0] = c->fit_big_count[0] = 0;
     // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
     const FrameParams &fp = c->params[(unsigned)(c->cursor[0] * c->cursor_mul + c->cursor_add) % (unsigned)c->n_params];
     const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
@@ -806,6 +806,16 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
 // running sum that starts at +0.0 stays bit-identical when +0.0 is added, and a padded element's product is +0.0).
 constexpr int kFitSeeds = 4, kFitLanes = 16, kFitCols = 4;
 constexpr int kFitStride = kGnCap + 4; // 236 floats: successive columns 16 B x 59 apart -> shifted by 11 x 16 B mod 256
+// LDS per wave decides how many waves of this kernel a CU holds (16.8 KB: nine), and it is sized for the longest list
+// a window can give (232) while nearly every group of four seeds stays far below that.  Launches batched over
+// handles -- enough waves to fill the machine several times -- therefore run the fit in two tiers: groups whose longest
+// list fits kFitSmallCap in a kernel with columns of that length (9.6 KB and fewer registers: sixteen waves per CU);
+// that kernel queues the few others (c->worklist, free by now; count in c->fit_big_count), and a second launch of a
+// handful of workgroups in the full-length form works the queue off -- normally it finds it empty.  Same arithmetic,
+// element for element; which tier a group takes changes nothing in its result.
+constexpr int kFitSmallStride = kFitSmallCap + 4; // 124 floats: columns 16 B x 31 apart -> shifted by 15 x 16 B mod 256
+constexpr int kFitLargeBlocks = 16;               // workgroups per handle working the queue off
+enum FitTier { kFitAll = 0, kFitSmall = 1, kFitLarge = 2 };
 // accumulator of lane gl of a group: (X column, Y column); columns 0..2 = p, 3 = residual, 4 = the homogeneous 1 -- a
 // shared block of eight 1.0f read at stride 0 instead of a column per seed (LDS per wave decides how many waves a CU
 // holds, and this kernel is short of waves).  gl 0..8 = H(a,b), a <= b, without H(3,3); gl 9 = H(3,3) = 2 x (number of
@@ -886,16 +896,18 @@ __device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *
     return 2.0 * acc;
 }
 
-template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
-    const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
-    __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][kFitStride];
-    __shared__ __attribute__((aligned(16))) float s_ones[8];
-    __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
+template <int TIER> struct FitShape {
+    static constexpr int kStride = TIER == kFitSmall ? kFitSmallStride : kFitStride;
+    static constexpr int kChunks = TIER == kFitSmall ? (kFitSmallCap + 63) / 64 : 4; // 64-element chunks a list can span
+};
+
+// the group of seeds s0 .. s0+3 on one wave
+template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *__restrict__ c, int s0,
+                                                             float (*s_col)[kFitCols][FitShape<TIER>::kStride], float *s_ones,
+                                                             double (*s_solver)[52]) {
+    constexpr int kChunks = FitShape<TIER>::kChunks;
     const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
     const int S = c->n_seed;
-    const int n_groups = (S + kFitSeeds - 1) / kFitSeeds;
-    const int s0 = (n_groups - 1 - blk.x) * kFitSeeds; // bottom rows (long lists) first, see seed_of_block
     const int s = s0 + g;
     const bool live = s < S;
     stamp(c, 4, s0, 0, lane);
@@ -928,6 +940,10 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const Dev
     int m_max = mg[0];
 #pragma unroll
     for (int q = 1; q < kFitSeeds; q++) m_max = mg[q] > m_max ? mg[q] : m_max;
+    if (TIER == kFitSmall && m_max > c->fit_small_cap) { // does not fit this tier's columns: queue it for the other
+        if (lane == 0) c->worklist[atomicAdd(c->fit_big_count, 1)] = s0 / kFitSeeds;
+        return;
+    }
     const int m8 = (m_max + 7) & ~7;
     float nx = hd.nx, ny = hd.ny, nz = hd.nz, nb = 0.0f;
     stamp(c, 4, s0, 1, lane);
@@ -967,11 +983,11 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const Dev
         const int xs = xcol == 4 ? 0 : 1, ys = ycol == 4 ? 0 : 1;
         wave_lds_sync();
         // this lane's points of every list (element k*64+lane of seed q), for the residuals
-        float pq[kFitSeeds][4][3];
+        float pq[kFitSeeds][kChunks][3];
 #pragma unroll
         for (int q = 0; q < kFitSeeds; q++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < kChunks; k++) {
                 const int i = k * 64 + lane;
 #pragma unroll
                 for (int col = 0; col < 3; col++) pq[q][k][col] = (k * 64 < mg[q] && i < m8) ? s_col[q][col][i] : 0.0f;
@@ -1005,7 +1021,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const Dev
 #pragma unroll
             for (int q = 0; q < kFitSeeds; q++) {
 #pragma unroll
-                for (int k = 1; k < 4; k++) {
+                for (int k = 1; k < kChunks; k++) {
                     if (k * 64 < mg[q]) { // wave-uniform
                         const int i = k * 64 + lane;
                         const bool valid = i < mg[q];
@@ -1104,6 +1120,24 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_fit(const Dev
     c->spawn_ok[s] = ok ? 1 : 0;
     c->fused_flag[s] = 0;
     if (g == 0) stamp(c, 4, s0, 5, 0);
+}
+
+template <bool BATCH, int TIER> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const BlockOf blk = block_of<BATCH>();
+    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][FitShape<TIER>::kStride];
+    __shared__ __attribute__((aligned(16))) float s_ones[8];
+    __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
+    if (TIER == kFitLarge) {
+        const int n_big = c->fit_big_count[0];
+        for (int e = blk.x; e < n_big; e += kFitLargeBlocks) {
+            fit_group<TIER>(c, c->worklist[e] * kFitSeeds, s_col, s_ones, s_solver);
+            wave_lds_sync();
+        }
+    } else {
+        const int n_groups = (c->n_seed + kFitSeeds - 1) / kFitSeeds;
+        fit_group<TIER>(c, (n_groups - 1 - blk.x) * kFitSeeds, s_col, s_ones, s_solver); // bottom rows (long lists) first, see seed_of_block
+    }
 }
 
 // ------------------------------------------------------------------------------ fuse surfels
@@ -1754,7 +1788,8 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     }
     hipLaunchStage(k_seed_points<false>, k_seed_points<true>, g_seed_wave, dim3(256));
     DSM_MARK();
-    hipLaunchStage(k_seed_fit<false>, k_seed_fit<true>, dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
+    hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitSmall>), dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
+    if (batched) hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitLarge>), dim3(kFitLargeBlocks), dim3(64));
     DSM_MARK();
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;

@@ -33,14 +33,29 @@ def short(name):
     return n
 
 
+def single_name(k):
+    """the frame kernels carry a trailing BATCH template argument; the one-subsequence instantiation (false) is
+    recorded under the plain name: k_update_seeds<true, false> -> k_update_seeds<true>, k_seed_fit<false> -> k_seed_fit"""
+    if not k.endswith(">") or k.startswith("k_repack_rows"):
+        return k
+    base, args = k[:-1].split("<", 1)
+    if base == "k_seed_fit":  # <BATCH, tier>: the one-subsequence launch has a single tier
+        return base
+    args = [a.strip() for a in args.split(",")]
+    if args[-1] == "false":
+        args = args[:-1]
+    return base + ("<" + ", ".join(args) + ">" if args else "")
+
+
 def main():
     fetch_dir, write_dir, out_path, cmd = sys.argv[1:5]
-    fetch = {short(k): v for k, v in per_kernel(fetch_dir, "FETCH_SIZE").items()}
-    write = {short(k): v for k, v in per_kernel(write_dir, "WRITE_SIZE").items()}
-    n = W * H
     # (launches batched over several subsequences: the calibration kernel's known bytes scale with the batch)
     nb = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-    cal_name = "k_assign<true, true>" if nb > 1 else ("k_assign<true, false>" if "k_assign<true, false>" in fetch else "k_assign<true>")
+    name = (lambda k: short(k)) if nb > 1 else (lambda k: single_name(short(k)))
+    fetch = {name(k): v for k, v in per_kernel(fetch_dir, "FETCH_SIZE").items()}
+    write = {name(k): v for k, v in per_kernel(write_dir, "WRITE_SIZE").items()}
+    n = W * H
+    cal_name = "k_assign<true, true>" if nb > 1 else "k_assign<true>"
     n *= nb
     cal_f = (5 * n / 1024.0) / fetch[cal_name]
     cal_w = (4 * n / 1024.0) / write[cal_name]
