@@ -228,7 +228,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
 #pragma unroll
         for (int t = 3; t >= 0; t--) {
             const int x = wx0 + 4 * q + t;
-            if (row_in && x >= x_lo && x < x_hi && (double)e[t] > 0.01) { hit = true; first = e[t]; }
+            if (row_in && x >= x_lo && x < x_hi && e[t] > flt_below(0.01)) { hit = true; first = e[t]; }
         }
     }
     // first row with a hit among the 16 lanes of this seed
@@ -236,7 +236,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
     const unsigned rows = (unsigned)(m >> (lane & ~(kInitLanes - 1))) & 0xffffu;
     const int src = (lane & ~(kInitLanes - 1)) + (rows ? __ffs((int)rows) - 1 : 0);
     const float scanned = __shfl(first, src);
-    if ((double)md < 0.01 && rows) md = scanned;
+    if (md < flt_above(0.01) && rows) md = scanned; // (double)md < 0.01
     if (!live || r != 0) return;
     c->core[s] = make_float4((float)ix, (float)iy, mi, md);
     c->inv_depth[s] = 1.0 / (double)md;
@@ -404,7 +404,7 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
     const float fn = (float)cnt;
     const float mi = (float)si / fn, mx = (float)sx / fn, my = (float)sy / fn;
     const float moved = fabsf(old.z - mi) + fabsf(old.x - mx) + fabsf(old.y - my);
-    const int stable = (double)moved < 0.2 ? 1 : 0;
+    const int stable = moved < flt_above(0.2) ? 1 : 0; // (double)moved < 0.2, in fp32 (dsm_math.h, flt_above)
     stamp(c, sweep, s, 3, lane);
     float md = 0.0f;
     // The kernel ends with its slowest wave, and that is a wave with a long list (its ordered sums are serial chains
@@ -414,6 +414,7 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
         // FF.cpp:530-556.  The loop-carried part of a Huber-Newton pass is only the ordered fp32 sum of
         // the per-element terms; residuals and their classification are computed lane-parallel.
         const double hr = c->huber;
+        const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
         pad_column(dl, nd, lane);
         pad_column(lt, nd, lane); // pad slots stay +0.0f: the passes below only write valid slots
         wave_lds_sync();
@@ -432,7 +433,7 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
                 const int idx = k * 64 + lane;
                 const bool valid = idx < nd;
                 const float r = md - dk[k];
-                const bool core = valid && (double)r < hr && (double)r > -hr;
+                const bool core = valid && fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
                 if (valid) lt[idx] = 2 * r;
                 tail[k] = __ballot(valid && !core);
                 pos[k] = __ballot(valid && !core && r > 0);
@@ -441,10 +442,10 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
             wave_lds_sync();
             const float a = huber_ordered_sum(lt, nd, tail, pos, hr);
             const float b = (float)(2 * n_core); // the reference adds 2.0f per core element: exact
-            const float delta = (float)((double)(-a) / ((double)b + 10.0));
+            const float delta = huber_newton_step(a, b);
             md = md + delta;
             wave_lds_sync();
-            if ((double)delta < 0.01 && (double)delta > -0.01) break;
+            if (fabsf(delta) < flt_above(0.01)) break; // (double)delta < 0.01 && (double)delta > -0.01
         }
     }
     stamp(c, sweep, s, 5, lane);
@@ -515,7 +516,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
         if (mem) {
             cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += pi[k];
         }
-        const bool dv = mem && (double)d > 0.1; // FF.cpp:508
+        const bool dv = mem && d > flt_below(0.1); // FF.cpp:508, (double)d > 0.1
         const unsigned long long m = __ballot(dv);
         if (dv) dl[nd + rank_below(m)] = d;
         nd += __popcll(m);
@@ -612,7 +613,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
         if (mem) {
             cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += s_ti[t];
         }
-        const bool dv = mem && (double)d > 0.1; // FF.cpp:508
+        const bool dv = mem && d > flt_below(0.1); // FF.cpp:508, (double)d > 0.1
         const unsigned long long m = __ballot(dv);
         if (dv) dl[nd + rank_below(m)] = d;
         nd += __popcll(m);
@@ -678,6 +679,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
     stamp(c, 3, s, 0, lane);
     const Intrinsics K = c->k;
     const double hr = c->huber;
+    const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
     const float4 core = c->core[s];
     const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
     float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2];
@@ -711,7 +713,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
             const float d2 = ex * ex + ey * ey;
             if (d2 > far2) far2 = d2;
         }
-        const bool ok = mem && (double)d > 0.05;
+        const bool ok = mem && d > flt_below(0.05); // (double)d > 0.05
         const unsigned long long m = __ballot(ok);
         if (ok) {
             const int pos = n + rank_below(m);
@@ -745,7 +747,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
                     d_down = dep[(y + 1) * pitch + x];
                 }
                 const float r = md - d;
-                ok = (double)r < hr && (double)r > -hr;
+                ok = fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
             }
             const unsigned long long m = __ballot(ok);
             if (ok) {
@@ -765,7 +767,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
         pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
         wave_lds_sync();
         stamp(c, 3, s, 2, lane);
-        if (!((double)((float)m_in / (float)n) < 0.8)) { // FF.cpp:862
+        if (!((float)m_in / (float)n < flt_above(0.8))) { // FF.cpp:862, (double)ratio < 0.8
             // sequential fp32 sums, FF.cpp:852-857 and 111-116
             // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
             const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in, true);
@@ -914,6 +916,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     const FrameParams &fp = frame_params(c);
     const Intrinsics K = c->k;
     const double hr = c->huber;
+    const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
     GnHeader hd;
     hd.m_in = 0;
     float4 core = make_float4(0, 0, 0, 0);
@@ -1012,7 +1015,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
             for (int q = 0; q < kFitSeeds; q++) {
                 const bool valid = lane < mg[q];
                 const float r = pq[q][0][0] * pn[q][0] + pq[q][0][1] * pn[q][1] + pq[q][0][2] * pn[q][2] + pn[q][3];
-                const int cls = huber_class(r, hr);
+                const int cls = huber_class32(r, hr_above);
                 // the residual column carries the tail sign for outliers (see fit_ordered_sum)
                 if (valid) s_col[q][3][lane] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
                 const unsigned long long mask = __ballot(valid && cls != 0);
@@ -1026,7 +1029,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
                         const int i = k * 64 + lane;
                         const bool valid = i < mg[q];
                         const float r = pq[q][k][0] * pn[q][0] + pq[q][k][1] * pn[q][1] + pq[q][k][2] * pn[q][2] + pn[q][3];
-                        const int cls = huber_class(r, hr);
+                        const int cls = huber_class32(r, hr_above);
                         if (valid) s_col[q][3][i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
                         const unsigned long long mask = __ballot(valid && cls != 0);
                         if (g == q) noncore[k] = mask;

@@ -27,6 +27,25 @@ struct Intrinsics {
     float fx, fy, cx, cy;
 };
 
+// A float against a double constant, compared in fp32.  The reference compares in double -- its thresholds are
+// double literals (0.1, 0.4 ...: none of them a float), so `x > 0.1` is `(double)x > 0.1` -- and on this hardware
+// the conversion alone costs four fp32 operations.  For a float x and c > 0 the outcome is that of a compare with
+// the float neighbouring c on the side of the relation:
+//     (double)x >  c  <=>  x >  flt_below(c)      (double)x <  c  <=>  x <  flt_above(c)
+//     (double)x <= c  <=>  x <= flt_below(c)      (double)x >= c  <=>  x >= flt_above(c)
+// flt_below(c) = the largest float <= c, flt_above(c) = the smallest float >= c: every float is a double, and
+// between those two there is no float, so x > c means x >= flt_above(c) > flt_below(c), and x > flt_below(c) means
+// x >= the next float up, which is > c (or c itself is a float and both are c).  NaN compares false either way, and
+// -c mirrors.  (tests/test_cpu.py walks the floats around every threshold used.)
+DSM_HD constexpr float flt_below(double c) {
+    const float f = (float)c; // round to nearest: off by at most one float
+    return (double)f <= c ? f : __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f) - 1u);
+}
+DSM_HD constexpr float flt_above(double c) {
+    const float f = (float)c;
+    return (double)f >= c ? f : __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f) + 1u);
+}
+
 // x / 100.0, correctly rounded, in three operations instead of a full fp64 divide expansion:
 // q0 = RN(x*r), e = x - 100*q0 (exact in one FMA), q = RN(q0 + e*r) with r = RN(1/100) is the
 // correctly rounded quotient (Markstein's theorem; 100 = 1.5625*2^6 has no all-ones significand).
@@ -64,7 +83,7 @@ DSM_HD bool pixel_cost(float sx, float sy, float si, bool seed_has_depth, double
 // to 24 bits equals rounding it once (Figueroa), so the correctly rounded fp32 divide gives the same bits.
 DSM_HD float pixel_inv_depth(float d) {
     float invd = 0.0f;
-    if ((double)d > 0.01) invd = 1.0f / d;
+    if (d > flt_below(0.01)) invd = 1.0f / d; // (double)d > 0.01
     return invd;
 }
 
@@ -116,22 +135,29 @@ DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, Loa
 
 // ------------------------------------------------- robust mean depth of a seed, FF.cpp:530-556
 // list[0..n) = member depths > 0.1 in window row-major order, sum = their sequential fp32 sum.
+// Newton step of the robust mean, FF.cpp:553: delta = (float)((double)(-a) / ((double)b + 10.0)), where b = 2 x (core
+// elements) is a small integer.  -a and b + 10 are both floats, and rounding the quotient of two 24-bit values first
+// to 53 >= 2*24+2 bits and then to 24 is rounding it once (Figueroa): the correctly rounded fp32 divide gives the
+// same bits as the double divide and the cast, at a third of the instructions.
+DSM_HD float huber_newton_step(float a, float b) { return (-a) / (b + 10.0f); }
+
 DSM_HD float huber_mean_depth(const float *list, int n, float sum, double huber) {
+    const float hr_above = flt_above(huber);
     float md = sum / (float)n;
     for (int it = 0; it < 5; it++) {
         float a = 0, b = 0;
         for (int k = 0; k < n; k++) {
             float r = md - list[k];
-            if ((double)r < huber && (double)r > -huber) {
+            if (fabsf(r) < hr_above) { // (double)r < huber && (double)r > -huber
                 a += 2 * r;
                 b += 2;
             } else {
                 a = (float)((double)a + (r > 0 ? huber : -1 * huber));
             }
         }
-        float delta = (float)((double)(-a) / ((double)b + 10.0));
+        float delta = huber_newton_step(a, b);
         md = md + delta;
-        if ((double)delta < 0.01 && (double)delta > -0.01) break;
+        if (fabsf(delta) < flt_above(0.01)) break; // (double)delta < 0.01 && (double)delta > -0.01
     }
     return md;
 }
@@ -147,7 +173,8 @@ DSM_HD void back_project(const Intrinsics &k, float u, float v, float d, float &
 // 1 <= x <= w-2 and 1 <= y <= h-2; returns false (normal stays 0) when rejected.
 DSM_HD bool pixel_normal(const Intrinsics &k, int x, int y, float d, float d_right, float d_down, float &nx,
                          float &ny, float &nz) {
-    if ((double)d < 0.1 || (double)d_right < 0.1 || (double)d_down < 0.1) return false;
+    constexpr float kMin = flt_above(0.1); // (double)d < 0.1
+    if (d < kMin || d_right < kMin || d_down < kMin) return false;
     float px, py, pz, rx, ry, rz, dx, dy, dz;
     back_project(k, (float)x, (float)y, d, px, py, pz);
     back_project(k, (float)(x + 1), (float)y, d_right, rx, ry, rz);
@@ -158,7 +185,7 @@ DSM_HD bool pixel_normal(const Intrinsics &k, int x, int y, float d, float d_rig
     float len = sqrtf(ax * ax + ay * ay + az * az);
     ax /= len; ay /= len; az /= len;
     float va = (ax * px + ay * py + az * pz) / sqrtf(px * px + py * py + pz * pz);
-    if ((double)va > -kAngleCos && (double)va < kAngleCos) return false;
+    if (fabsf(va) < flt_above(kAngleCos)) return false; // (double)va > -kAngleCos && (double)va < kAngleCos
     nx = ax; ny = ay; nz = az;
     return true;
 }
@@ -269,11 +296,12 @@ DSM_HD double gn_term_add(double acc, const GnTerm &t, const float p[4], float r
 
 // The same sums in the form the HIP kernel streams them: residual class first, then one branch-free
 // term per (element, accumulator).  X,Y = (p_a, p_b) for H(a,b) and (r, p_a) for J(a).
-DSM_HD int huber_class(float r, double hr) {
-    if ((double)r < hr && (double)r > -1 * hr) return 0; // core
-    if ((double)r >= hr) return 1;                       // upper tail
-    if ((double)r <= -1 * hr) return 2;                  // lower tail
-    return 3;                                            // NaN: contributes nothing
+// (hr_above = flt_above(hr): the reference's double compares of the float residual, in fp32)
+DSM_HD int huber_class32(float r, float hr_above) {
+    if (fabsf(r) < hr_above) return 0; // core:       (double)r < hr && (double)r > -hr
+    if (r >= hr_above) return 1;       // upper tail: (double)r >= hr
+    if (r <= -hr_above) return 2;      // lower tail: (double)r <= -hr
+    return 3;                          // NaN: contributes nothing
 }
 DSM_HD double gn_term(bool is_jacobian, float X, float Y, int cls, double hr) {
     const double core = (double)(2 * X * Y);

@@ -44,7 +44,7 @@ void init_seeds(Emu &e) {
         int gx = s % e.gw, gy = s / e.gw;
         int ix = gx * kCell + kCell / 2, iy = gy * kCell + kCell / 2;
         float md = e.D(ix, iy);
-        if ((double)md < 0.01) {
+        if (md < flt_above(0.01)) { // (double)md < 0.01
             int x0 = ix - kCell, y0 = iy - kCell, x1 = x0 + 2 * kCell, y1 = y0 + 2 * kCell;
             if (x0 < 0) x0 = 0;
             if (y0 < 0) y0 = 0;
@@ -53,7 +53,7 @@ void init_seeds(Emu &e) {
             bool found = false;
             for (int y = y0; y < y1 && !found; y++)
                 for (int x = x0; x < x1; x++)
-                    if ((double)e.D(x, y) > 0.01) { md = e.D(x, y); found = true; break; }
+                    if (e.D(x, y) > flt_below(0.01)) { md = e.D(x, y); found = true; break; }
         }
         e.core[s] = {(float)ix, (float)iy, e.I(ix, iy), md};
         e.inv_depth[s] = 1.0 / (double)md;
@@ -120,7 +120,7 @@ void update_seeds(Emu &e, int sweep) {
             if (!in || e.label[e.key(x, y)] != s) continue;
             cnt++; sx += x; sy += y; si += (int)e.img[(size_t)y * e.img_step + x];
             const float d = e.D(x, y);
-            if ((double)d > 0.1) dl[nd++] = d;
+            if (d > flt_below(0.1)) dl[nd++] = d; // (double)d > 0.1
         }
         if (cnt == 0) {
             int &fe = e.first_empty[sweep][chunk_of(e.S, s)];
@@ -138,7 +138,7 @@ void update_seeds(Emu &e, int sweep) {
             md = huber_mean_depth(dl, nd, sum, e.huber);
         }
         e.stage[s] = {mx, my, mi, md};
-        e.stable_stage[s] = (double)moved < 0.2 ? 1 : 0;
+        e.stable_stage[s] = moved < flt_above(0.2) ? 1 : 0; // (double)moved < 0.2
     }
     for (int s = 0; s < e.S; s++) { // commit
         if (e.tmin[s] == kIntMax) continue;
@@ -168,7 +168,7 @@ void seed_planes(Emu &e) {
             const float d2 = ex * ex + ey * ey;
             if (d2 > far2) far2 = d2;
             const float d = e.D(x, y);
-            if ((double)d > 0.05) { ld[n] = d; lx[n] = x; ly[n] = y; n++; }
+            if (d > flt_below(0.05)) { ld[n] = d; lx[n] = x; ly[n] = y; n++; }
         }
         dsm_seed out;
         memset(&out, 0, sizeof out);
@@ -179,7 +179,7 @@ void seed_planes(Emu &e) {
             int m = 0;
             for (int i = 0; i < n; i++) {
                 const float r = md - ld[i];
-                if (!((double)r < e.huber && (double)r > -e.huber)) continue;
+                if (!(fabsf(r) < flt_above(e.huber))) continue;
                 float nx = 0, ny = 0, nz = 0;
                 const int x = lx[i], y = ly[i];
                 if (x >= 1 && x <= e.w - 2 && y >= 1 && y <= e.h - 2)
@@ -188,7 +188,7 @@ void seed_planes(Emu &e) {
                 back_project(e.K, (float)x, (float)y, ld[i], lp[m * 3], lp[m * 3 + 1], lp[m * 3 + 2]);
                 m++;
             }
-            if (!((double)((float)m / (float)n) < 0.8)) {
+            if (!((float)m / (float)n < flt_above(0.8))) {
                 float nx = 0, ny = 0, nz = 0, nb = 0, mx = 0, my = 0, mz = 0;
                 for (int i = 0; i < m; i++) {
                     nx += ln[i * 3]; ny += ln[i * 3 + 1]; nz += ln[i * 3 + 2];
@@ -204,7 +204,7 @@ void seed_planes(Emu &e) {
                     int cls[256];
                     for (int i = 0; i < m; i++) {
                         res[i] = lp[i * 3] * nx + lp[i * 3 + 1] * ny + lp[i * 3 + 2] * nz + nb;
-                        cls[i] = huber_class(res[i], e.huber);
+                        cls[i] = huber_class32(res[i], flt_above(e.huber));
                     }
                     for (int lane = 0; lane < 20; lane++) {
                         const bool is_j = lane >= 16;
@@ -344,6 +344,43 @@ int emu_div100_mismatches(const float *x, int n) {
     for (int i = 0; i < n; i++) {
         const double a = (double)x[i] / 100.0, b = div_by_100((double)x[i]);
         bad += memcmp(&a, &b, 8) != 0;
+    }
+    return bad;
+}
+// fp32 forms of the reference's double-typed compares (dsm_math.h, flt_below / flt_above): every float within
+// `reach` floats of +-c, plus the specials, through all four relations against c and -c
+int emu_threshold_mismatches(double c, int reach) {
+    int bad = 0;
+    const float lo = flt_below(c), hi = flt_above(c);
+    bad += !((double)lo <= c && (double)hi >= c);
+    bad += !(lo == hi || nextafterf(lo, INFINITY) == hi); // neighbours, or c is a float
+    float specials[] = {0.0f, -0.0f, INFINITY, -INFINITY, NAN, 1e-45f, -1e-45f, 3.4e38f, -3.4e38f};
+    for (int sign = -1; sign <= 1; sign += 2) {
+        float x = (float)c * (float)sign;
+        for (int i = 0; i < reach; i++) x = nextafterf(x, -INFINITY);
+        for (int i = 0; i <= 2 * reach + (int)(sizeof(specials) / sizeof(float)); i++) {
+            const float v = i <= 2 * reach ? x : specials[i - 2 * reach - 1];
+            const double d = (double)v;
+            bad += (d > c) != (v > lo);
+            bad += (d < c) != (v < hi);
+            bad += (d <= c) != (v <= lo);
+            bad += (d >= c) != (v >= hi);
+            bad += (d > -c) != (v > -hi);
+            bad += (d < -c) != (v < -lo);
+            bad += (d < c && d > -c) != (fabsf(v) < hi);
+            x = nextafterf(x, INFINITY);
+        }
+    }
+    return bad;
+}
+// the Newton step of the robust mean in fp32 vs the reference's double expression (FF.cpp:553)
+int emu_newton_step_mismatches(const float *a, const int *n_core, int n) {
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        float b = 0;
+        for (int k = 0; k < n_core[i]; k++) b += 2; // as the reference accumulates it
+        const float ref = (float)((double)(-a[i]) / ((double)b + 10.0)), got = huber_newton_step(a[i], b);
+        bad += memcmp(&ref, &got, 4) != 0 && !(ref != ref && got != got);
     }
     return bad;
 }

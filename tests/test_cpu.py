@@ -216,6 +216,24 @@ def test_div_by_100_is_the_ieee_quotient(hostemu_lib):
     assert emu.emu_div100_mismatches(x.ctypes.data, len(x)) == 0
 
 
+def test_double_typed_compares_in_fp32(hostemu_lib):
+    """dsm_math.h compares floats against the reference's double thresholds in fp32 (flt_below / flt_above) and takes
+    the Newton step of the robust mean as an fp32 divide: same outcome as the double expressions for every float
+    around every threshold the path uses, and on random sums of every exponent."""
+    emu = C.CDLL(hostemu_lib)
+    emu.emu_threshold_mismatches.argtypes = [C.c_double, C.c_int]
+    for c in (0.01, 0.05, 0.1, 0.2, 0.4, 0.8, 0.5, 0.25, 1.0, 0.3, 1e-3, 7.0):
+        assert emu.emu_threshold_mismatches(c, 5000) == 0, c
+    emu.emu_newton_step_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(9)
+    bits = rng.integers(0, 2 ** 32, 3_000_000, dtype=np.uint64).astype(np.uint32)
+    a = np.concatenate([bits.view(np.float32), rng.normal(0, 40, 3_000_000).astype(np.float32),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3e38], np.float32)])
+    a = np.ascontiguousarray(a, np.float32)
+    n_core = np.ascontiguousarray(rng.integers(0, 257, len(a)), np.int32)
+    assert emu.emu_newton_step_mismatches(a.ctypes.data, n_core.ctypes.data, len(a)) == 0
+
+
 def test_stable_skip_fixed_point_bruteforce():
     """The tmin fixed point of k_assign/k_resolve/k_apply vs the reference's sequential scan
     (FF.cpp:400,445,450) on random (old label, pick, stable) instances."""
