@@ -83,6 +83,60 @@ def test_long_sequence_kitti_golden(mods, gold):
     ff.close()
 
 
+def test_long_sequence_kitti_golden_batched(mods, gold):
+    """The headline configuration of bench.py against the same vectors: EIGHT handles advancing in lockstep through the
+    200 frames at 1226x370, every kernel launched once for all of them (one handle per XCD, the plane fit in its two
+    tiers).  Handle b is 7 - b frames ahead of handle 7, so no two ever work on the same frame; every handle's map
+    after its own 50th / 100th / 150th / 200th frame is the reference TU's, and so are its labels after its 200th."""
+    api, synth, ob = mods
+    case = gold["sequence"]
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    period = scene.frames_per_period
+    n, B = case["frames"], 8
+    frames = list(synth.sequence(cam, scene, n + B))  # the leaders run a few frames past the end while the others finish
+    step = case["checkpoint_every"]
+    plan = api.FusionFunctions.pack_replay([f[0] % period for f in frames], [f[4] for f in frames], [f[3] for f in frames])
+    lead = [B - 1 - b for b in range(B)]
+    handles = []
+    for b in range(B):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20, pipeline_depth=1)
+        for t in range(period):
+            ff.frame_upload(t, frames[t][1], frames[t][2])
+        # a batch needs its handles' parameter rings in step: every handle has B - 1 frames behind it when the batch
+        # starts -- throw-away frames first (their map is discarded), then the handle's head start on the sequence
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        waste = B - 1 - lead[b]
+        if waste:
+            ff.replay_enqueue(plan[0][:waste], plan[1][:waste], plan[2][:waste])
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        if lead[b]:
+            ff.replay_enqueue(plan[0][:lead[b]], plan[1][:lead[b]], plan[2][:lead[b]])
+        ff.synchronize()
+        handles.append(ff)
+    batch = api.Batch(handles)
+    done = list(lead)
+    checked = [[] for _ in range(B)]
+    while min(done) < n:
+        m = min(step - d % step for d in done)  # up to the next checkpoint of whichever handle is closest to one
+        s_, r_, p_, _ = api.Batch.pack([(plan[0][done[b]:done[b] + m], plan[1][done[b]:done[b] + m], plan[2][done[b]:done[b] + m])
+                                        for b in range(B)])
+        batch.replay_enqueue(s_, r_, p_, m)
+        batch.synchronize()
+        for b in range(B):
+            done[b] += m
+            if done[b] % step == 0 and done[b] <= n:
+                got = handles[b].map_download()
+                assert len(got) == case["per_frame"][done[b] - 1]["n_local"], (b, done[b])
+                assert map_sha(got, api.SURFEL_DTYPE) == case["map_sha256"][str(done[b])], f"handle {b}: map after {done[b]} frames"
+                if done[b] == n:
+                    assert hashlib.sha256(handles[b].labels().tobytes()).hexdigest() == case["per_frame"][-1]["labels_sha256"]
+                checked[b].append(done[b])
+    assert all(c == [step * (i + 1) for i in range(n // step)] for c in checked), checked
+    batch.close()
+    for ff in handles:
+        ff.close()
+
+
 def _large_case(mods, gold_rows, case, dropin_trial=None):
     api, synth, ob = mods
     cam = getattr(synth, case["camera"])
