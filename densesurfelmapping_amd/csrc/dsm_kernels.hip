@@ -1173,6 +1173,37 @@ __device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s
     }
 }
 
+// The same copy split in two: the loads of a block of records are issued into registers one loop trip ahead and landed
+// in LDS when the trip starts.  A block that loads, works and stores in turn has bytes in flight for a fraction of its
+// life only, and HBM bandwidth is bytes in flight over latency; with the next block's records on their way during the
+// gathers, the arithmetic and the store-back, a CU keeps about twice as many.
+// (three named vectors, not an array: an aggregate indexed in a loop ends up in scratch memory here)
+struct RecRegs {
+    float4 v0, v1, v2; // 256 records = 704 16-byte vectors: 2.75 per thread
+};
+__device__ __forceinline__ RecRegs records_issue(const dsm_surfel *src, int cnt, int tid) {
+    const int n_dw = cnt * kRecDw;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    // unconditional (a vector beyond the block re-reads vector 0): no branch to wait behind
+    RecRegs p;
+    p.v0 = s4[tid * 4 + 4 <= n_dw ? tid : 0];
+    p.v1 = s4[(tid + 256) * 4 + 4 <= n_dw ? tid + 256 : 0];
+    p.v2 = s4[(tid + 512) * 4 + 4 <= n_dw ? tid + 512 : 0];
+    return p;
+}
+__device__ __forceinline__ void records_land_one(float *s_rec, const float4 &val, const float *s1, int n_dw, int v) {
+    if (v * 4 + 4 <= n_dw) reinterpret_cast<float4 *>(s_rec)[v] = val;
+    else if (v * 4 < n_dw) // ragged last vector of the array
+        for (int e = v * 4; e < n_dw; e++) s_rec[e] = s1[e];
+}
+__device__ __forceinline__ void records_land(float *s_rec, const RecRegs &p, const dsm_surfel *src, int cnt, int tid) {
+    const int n_dw = cnt * kRecDw;
+    const float *s1 = reinterpret_cast<const float *>(src);
+    records_land_one(s_rec, p.v0, s1, n_dw, tid);
+    records_land_one(s_rec, p.v1, s1, n_dw, tid + 256);
+    records_land_one(s_rec, p.v2, s1, n_dw, tid + 512);
+}
+
 template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
     const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
@@ -1186,10 +1217,14 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
     fc.baseline = c->baseline; fc.disp_err = c->disp_err; fc.min_tol = c->min_tol;
     fc.w = c->w; fc.h = c->h;
     const int ref_idx = fp.ref_idx;
-    for (int base = blk.x * 256; base < M; base += gridDim.x * 256) {
+    const int stride = gridDim.x * 256;
+    RecRegs ahead = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if ((int)blk.x * 256 < M) ahead = records_issue(c->local + blk.x * 256, M - blk.x * 256 < 256 ? M - blk.x * 256 : 256, tid);
+    for (int base = blk.x * 256; base < M; base += stride) {
         const int cnt = M - base < 256 ? M - base : 256;
-        records_to_lds(s_rec, c->local + base, cnt, tid);
+        records_land(s_rec, ahead, c->local + base, cnt, tid);
         __syncthreads();
+        if (base + stride < M) ahead = records_issue(c->local + base + stride, M - base - stride < 256 ? M - base - stride : 256, tid);
         bool hole = false, changed = false;
         if (tid < cnt) {
             float *r = s_rec + tid * kRecDw;
@@ -1564,7 +1599,13 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
     __shared__ __attribute__((aligned(16))) float s_rec[256 * 11];
     const int n = n_ptr ? n_ptr[0] : n_fixed;
     const int tid = threadIdx.x;
-    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+    // without untouched groups to skip, every block is read: its records are fetched one trip ahead (records_issue)
+    const bool stream_all = group_on == nullptr;
+    const int stride = gridDim.x * 256;
+    RecRegs ahead = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (stream_all && (int)blockIdx.x * 256 < n)
+        ahead = records_issue(surfels + blockIdx.x * 256, n - (int)blockIdx.x * 256 < 256 ? n - (int)blockIdx.x * 256 : 256, tid);
+    for (int base = blockIdx.x * 256; base < n; base += stride) {
         const int cnt = n - base < 256 ? n - base : 256;
         if (group_on) { // block-uniform: skip blocks that only hold untouched groups
             const int g0 = warp_group_of(group_offsets, n_groups, base), g1 = warp_group_of(group_offsets, n_groups, base + cnt - 1);
@@ -1577,14 +1618,20 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
         float4 *dst = reinterpret_cast<float4 *>(surfels + base);
         float4 *lds4 = reinterpret_cast<float4 *>(s_rec);
         const bool whole = cnt == 256 || ((cnt * 11) & 3) == 0;
-        for (int v = tid; v < n_vec; v += 256) {
-            if (whole || v < n_vec - 1) lds4[v] = src[v];
-            else { // ragged last vector of the array: dword by dword
-                const float *s1 = reinterpret_cast<const float *>(surfels + base);
-                for (int e = v * 4; e < cnt * 11; e++) s_rec[e] = s1[e];
+        if (stream_all) {
+            records_land(s_rec, ahead, surfels + base, cnt, tid);
+        } else {
+            for (int v = tid; v < n_vec; v += 256) {
+                if (whole || v < n_vec - 1) lds4[v] = src[v];
+                else { // ragged last vector of the array: dword by dword
+                    const float *s1 = reinterpret_cast<const float *>(surfels + base);
+                    for (int e = v * 4; e < cnt * 11; e++) s_rec[e] = s1[e];
+                }
             }
         }
         __syncthreads();
+        if (stream_all && base + stride < n)
+            ahead = records_issue(surfels + base + stride, n - base - stride < 256 ? n - base - stride : 256, tid);
         if (tid < cnt) {
             const float *m = mats ? mats : single.m;
             bool on = true;
