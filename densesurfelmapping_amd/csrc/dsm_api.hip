@@ -697,6 +697,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.spawn_rec, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_ok, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.fused_flag, (size_t)c.n_seed));
+        CREATE_TRY(dev_alloc(h, &q.seed_weight, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_idx, (size_t)c.n_seed));
         int32_t *ps = nullptr; // work_count, cursor, assign_done, fit_big_count
         CREATE_TRY(dev_alloc(h, &ps, 64));

@@ -80,6 +80,7 @@ struct DeviceCtx {
     dsm_surfel *spawn_rec; // [S]
     uint8_t *spawn_ok;     // [S]
     uint8_t *fused_flag;   // [S] set by k_fuse_surfels (besides the byte in `seeds`)
+    float *seed_weight;    // [S] depth_weight(mean_depth) of the final seed, for k_fuse_surfels
     int32_t *spawn_idx;    // [S] seeds that do create a surfel, ascending
     // surfel map
     dsm_surfel *local;

@@ -167,9 +167,61 @@ template <bool BATCH> __device__ __forceinline__ BlockOf block_of() {
 #endif
 }
 
+// A pointer loaded from memory is a generic pointer to the compiler: loads through it are flat_load (address-space check
+// per access, 64-bit vector address arithmetic, and a wait that couples them to the LDS queue) instead of global_load.
+// Kernel arguments are known to be global; the context of a batched launch, read from the batch's array, is not --
+// it is copied out once with every pointer rebuilt as a global one (through an integer: a plain cast there and back
+// is folded away before the address-space inference sees it).
+template <typename T> __device__ __forceinline__ T *as_global(T *p) {
+    return (T *)(__attribute__((address_space(1))) T *)(unsigned long long)p;
+}
+__device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
+    DeviceCtx o = *as_global(src);
+#define DSM_G(f) o.f = as_global(o.f)
+    DSM_G(img_base);
+    DSM_G(depth_base);
+    DSM_G(label);
+    DSM_G(label_alt);
+    DSM_G(assign_done);
+    DSM_G(cand);
+    DSM_G(core);
+    DSM_G(inv_depth);
+    DSM_G(core_stage);
+    DSM_G(stable_stage);
+    DSM_G(tmin);
+    DSM_G(first_empty);
+    DSM_G(worklist);
+    DSM_G(work_count);
+    DSM_G(fit_big_count);
+    DSM_G(gn_hdr);
+    DSM_G(gn_pts);
+    DSM_G(seeds);
+    DSM_G(spawn_rec);
+    DSM_G(spawn_ok);
+    DSM_G(fused_flag);
+    DSM_G(spawn_idx);
+    DSM_G(local);
+    DSM_G(fresh);
+    DSM_G(n_local);
+    DSM_G(n_local_next);
+    DSM_G(n_new);
+    DSM_G(hole_mask);
+    DSM_G(wave_prefix);
+    DSM_G(holes);
+    DSM_G(n_holes);
+    DSM_G(params);
+    DSM_G(cursor);
+    DSM_G(status);
+    DSM_G(cur);
+    DSM_G(stamps);
+    DSM_G(seed_weight);
+#undef DSM_G
+    return o;
+}
+
 __device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur->p; }
-__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return c->cur->img; }
-__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return c->cur->dep; }
+__device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return as_global(c->cur->img); }
+__device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return as_global(c->cur->dep); }
 
 // ------------------------------------------------------------------------------ init seeds
 // FF.cpp:577-629.  A seed whose centre pixel has no depth takes the first depth > 0.01 of its clipped 16x16 window
@@ -180,7 +232,9 @@ __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const Fr
 constexpr int kInitLanes = 16, kInitSeedsPerBlock = 256 / kInitLanes;
 template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     const int tid = threadIdx.x, lane = lane_id();
     const int r = tid & (kInitLanes - 1);
     const int s = blk.x * kInitSeedsPerBlock + tid / kInitLanes;
@@ -277,7 +331,9 @@ __device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
 
 template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
     const FrameParams &fp = frame_params(c);
@@ -342,7 +398,9 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
 // multi-XCD part -- and was 10x slower than the extra launch.)
 template <bool BATCH> __global__ __launch_bounds__(256) void k_resolve(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     resolve_worklist(c, ((sweep - 1) & 1) ? c->label_alt : c->label);
 }
 
@@ -458,7 +516,9 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
 
 template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -624,7 +684,9 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
 template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     const int s = blk.x * 256 + threadIdx.x;
     if (s == 0) c->work_count[0] = 0;
     if (s >= c->n_seed) return;
@@ -668,7 +730,9 @@ constexpr int kColStride = kWin * kWin + 4;
 
 template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = seed_of_block(blk.x, wv, c->gw, c->gh);
@@ -1122,12 +1186,15 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     }
     c->spawn_ok[s] = ok ? 1 : 0;
     c->fused_flag[s] = 0;
+    c->seed_weight[s] = depth_weight(out.mean_depth); // FF.cpp:274: what a surfel fusing into this seed weighs it with
     if (g == 0) stamp(c, 4, s0, 5, 0);
 }
 
 template <bool BATCH, int TIER> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][FitShape<TIER>::kStride];
     __shared__ __attribute__((aligned(16))) float s_ones[8];
     __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
@@ -1206,7 +1273,9 @@ __device__ __forceinline__ void records_land(float *s_rec, const RecRegs &p, con
 
 template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ __attribute__((aligned(16))) float s_rec[256 * kRecDw];
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
@@ -1216,7 +1285,17 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
     fc.k = c->k; fc.far_d = c->far_d; fc.near_d = c->near_d;
     fc.baseline = c->baseline; fc.disp_err = c->disp_err; fc.min_tol = c->min_tol;
     fc.w = c->w; fc.h = c->h;
+    fuse_const_prepare(fc);
     const int ref_idx = fp.ref_idx;
+    // the two matrices once, into scalar registers: read through `fp` inside the loop they are fetched again every trip
+    // (the compiler cannot rule out that the stores to the map alias them), a dependent round trip before a surfel can
+    // even be projected
+    float inv[16], pose[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        inv[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fp.inv[q])));
+        pose[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fp.pose[q])));
+    }
     const int stride = gridDim.x * 256;
     RecRegs ahead = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     if ((int)blk.x * 256 < M) ahead = records_issue(c->local + blk.x * 256, M - blk.x * 256 < 256 ? M - blk.x * 256 : 256, tid);
@@ -1234,19 +1313,23 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
             e.update_times = __float_as_int(r[9]); e.last_update = __float_as_int(r[10]);
             int ui, vi;
             float pc[3], nc[3];
-            FuseOutcome oc = fuse_project(fc, ref_idx, fp.inv, e, ui, vi, pc, nc);
+            FuseOutcome oc = fuse_project(fc, ref_idx, inv, e, ui, vi, pc, nc);
             if (oc == kFuseNeedPixel) {
                 const int p = vi * c->pitch + ui;
                 const int sidx = c->label[p];
                 SeedView sd = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // label -1 (ragged border): the all-zero seed, see has_candidate_cell
+                float w1 = 0.0f;
                 if (sidx >= 0) {
+                    w1 = c->seed_weight[sidx];
                     const dsm_seed *sp = &c->seeds[sidx];
                     sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
                     sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
                     sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
                 }
-                oc = fuse_update(fc, ref_idx, fp.pose, e, pc, nc, dep[p], sd);
-                if (oc == kFuseFused) { c->seeds[sidx].fused = 1; c->fused_flag[sidx] = 1; }
+                oc = fuse_update(fc, ref_idx, pose, e, pc, nc, dep[p], sd, w1);
+                // the seed's `fused` mark: idempotent, but ~60 surfels fuse into a seed and a byte store into a line that
+                // thousands of lanes are writing is a read-modify-write in L2 -- look first (a stale 0 only repeats the store)
+                if (oc == kFuseFused && c->fused_flag[sidx] == 0) { c->seeds[sidx].fused = 1; c->fused_flag[sidx] = 1; }
             }
             if (oc == kFuseDeleted) {
                 r[9] = __int_as_float(0);
@@ -1542,7 +1625,9 @@ __device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c,
 
 template <bool BATCH> __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int with_compaction) {
     const BlockOf blk = block_of<BATCH>();
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blk.z : &ctx;
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
     __shared__ int s_idx[kTailFastSeeds], s_refill[kTailFastSeeds];
@@ -1703,12 +1788,27 @@ __global__ void k_append(const DeviceCtx ctx, int n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) c->n_local[0] = c->n_local[0] + n;
 }
 
+// workgroups of `kernel` the current device holds at once (occupancy x CUs), cached per kernel and device
+template <typename K> static int resident_blocks(K kernel, int block_size) {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_size, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached[dev] = per_cu * cus;
+    }
+    return cached[dev];
+}
+
 hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, const float *d_mats, const float *single16,
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st, const uint8_t *d_group_on,
                        float4 *d_cloud) {
     int blocks = (n_upper + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int cap = resident_blocks(k_warp, 256); // see launch_frame, fuse_blocks
+    if (blocks > cap) blocks = cap;
     WarpMat one;
     for (int i = 0; i < 16; i++) one.m[i] = single16 ? single16[i] : 0.0f;
     hipLaunchKernelGGL(k_warp, dim3(blocks), dim3(256), 0, st, surfels, n_ptr, n_fixed, d_mats, one, d_offsets, n_groups,
@@ -1841,9 +1941,13 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitSmall>), dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
     if (batched) hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitLarge>), dim3(kFitLargeBlocks), dim3(64));
     DSM_MARK();
+    // grid-stride over the map with as many workgroups as the device holds at once: with more, the ones that start
+    // late run all their trips after the others have finished theirs (2 048 against 1 280 resident cost 76 instead of
+    // 61 us at 2 M surfels)
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;
-    if (fuse_blocks > 2048) fuse_blocks = 2048;
+    const int fuse_cap = batched ? resident_blocks(k_fuse_surfels<true>, 256) : resident_blocks(k_fuse_surfels<false>, 256);
+    if (fuse_blocks > fuse_cap) fuse_blocks = fuse_cap;
     hipLaunchStage(k_fuse_surfels<false>, k_fuse_surfels<true>, dim3(fuse_blocks), dim3(256));
     DSM_MARK();
     hipLaunchStage(k_frame_tail<false>, k_frame_tail<true>, dim3(1), dim3(1024), with_compaction ? 1 : 0);

@@ -384,9 +384,41 @@ struct FuseConst {
     float far_d, near_d;
     double baseline, disp_err, min_tol;
     int w, h;
+    // derived by fuse_const_prepare()
+    float cam_f;                 // camera_focal(k)
+    bool tol32;                  // the depth tolerance may be evaluated in fp32 (below)
+    float tol_den, tol_scale;    // baseline * cam_f and disp_err as floats, when tol32
+    float min_tol_above, min_tol_f;
 };
 
 enum FuseOutcome { kFuseSkip = 0, kFuseDeleted = 1, kFuseFused = 2, kFuseNeedPixel = 3 };
+
+// Depth tolerance of the association, FF.cpp:250-253:  tol = z*z / (BASELINE * camera_f) * DISPARITY_ERROR  evaluated
+// in double (the macros are double literals) and assigned to a float, then clamped from below by MIN_TOLERATE_DIFF.
+// When BASELINE * (double)camera_f is itself a float value and DISPARITY_ERROR a power of two -- the reference's
+// two constant sets: 0.5 and 4.0, 0.08 and 1.0 with the 525-pixel focal length -- this is an fp32 expression: scaling
+// by a power of two commutes with rounding, and rounding the quotient of two floats first to 53 >= 2*24+2 bits and
+// then to 24 bits is rounding it once (Figueroa), so  tol = (z*z / den_f) * scale_f  has the same bits (operands kept
+// away from the subnormal range by the near plane).  Any other constant set takes the double expression.
+DSM_HD void fuse_const_prepare(FuseConst &c) {
+    c.cam_f = camera_focal(c.k);
+    const double den = c.baseline * (double)c.cam_f;
+    const float den_f = (float)den;
+    const uint64_t scale_bits = __builtin_bit_cast(uint64_t, c.disp_err);
+    const bool scale_pow2 = c.disp_err >= 1.0 / 1048576.0 && c.disp_err <= 1048576.0 && (scale_bits & 0x000fffffffffffffull) == 0;
+    c.tol32 = (double)den_f == den && den >= 1e-6 && den <= 1e6 && scale_pow2 && c.near_d >= 1e-3f;
+    c.tol_den = den_f;
+    c.tol_scale = (float)c.disp_err;
+    c.min_tol_above = flt_above(c.min_tol);
+    c.min_tol_f = (float)c.min_tol;
+}
+DSM_HD float fuse_depth_tolerance(const FuseConst &c, float z) {
+    float tol;
+    if (c.tol32) tol = (z * z) / c.tol_den * c.tol_scale;
+    else tol = (float)((double)(z * z) / (c.baseline * (double)c.cam_f) * c.disp_err);
+    // tol = (float)((double)tol < min_tol ? min_tol : (double)tol)
+    return tol < c.min_tol_above ? c.min_tol_f : tol;
+}
 
 // Stage 1 of fuse_surfels_kernel (FF.cpp:205-238): pruning and projection.  Returns kFuseNeedPixel
 // with (ui,vi) and camera-frame position/normal when the surfel lands inside the image.
@@ -409,33 +441,36 @@ DSM_HD FuseOutcome fuse_project(const FuseConst &c, int ref_idx, const float *in
 }
 
 // Stage 2 (FF.cpp:239-311) given the depth at the projected pixel and the seed owning it.
+// (c prepared by fuse_const_prepare; w1 = depth_weight(sd.mean_depth), which k_seed_fit leaves per seed: two double
+// divides that every surfel fusing into the seed would repeat)
 DSM_HD FuseOutcome fuse_update(const FuseConst &c, int ref_idx, const float *pose, Surfel &e, const float pc[3],
-                               const float nc[3], float pix_depth, const SeedView &sd) {
+                               const float nc[3], float pix_depth, const SeedView &sd, float w1) {
     if ((double)pc[2] < (double)pix_depth - 1.0) {
         e.update_times = 0;
         return kFuseDeleted;
     }
     if (sd.nx == 0 && sd.ny == 0 && sd.nz == 0) return kFuseSkip;
-    if ((double)sd.view_cos < kAngleCos) return kFuseSkip;
-    float cam_f = camera_focal(c.k);
-    float tol = (float)((double)(pc[2] * pc[2]) / (c.baseline * (double)cam_f) * c.disp_err);
-    tol = (float)((double)tol < c.min_tol ? c.min_tol : (double)tol);
+    if (sd.view_cos < flt_above(kAngleCos)) return kFuseSkip; // (double)view_cos < MAX_ANGLE_COS
+    const float cam_f = c.cam_f;
+    const float tol = fuse_depth_tolerance(c, pc[2]);
     if (pc[2] < sd.mean_depth - tol) return kFuseSkip;
     if (pc[2] > sd.mean_depth + tol) return kFuseSkip;
     float ncos = nc[0] * sd.nx + nc[1] * sd.ny + nc[2] * sd.nz;
-    if ((double)ncos < kAngleCos) {
+    if (ncos < flt_above(kAngleCos)) { // (double)ncos < MAX_ANGLE_COS
         e.update_times = 0;
         return kFuseDeleted;
     }
-    float w0 = e.weight, w1 = depth_weight(sd.mean_depth), ws = w0 + w1;
+    float w0 = e.weight, ws = w0 + w1;
     float sc[3] = {sd.px, sd.py, sd.pz}, sw[3];
     xform_point(pose, sc, sw);
     float fpx = (e.px * w0 + w1 * sw[0]) / ws, fpy = (e.py * w0 + w1 * sw[1]) / ws, fpz = (e.pz * w0 + w1 * sw[2]) / ws;
     float fn[3] = {nc[0] * w0 + w1 * sd.nx, nc[1] * w0 + w1 * sd.ny, nc[2] * w0 + w1 * sd.nz};
-    double len = (double)sqrtf(fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2]);
-    fn[0] = (float)((double)fn[0] / len);
-    fn[1] = (float)((double)fn[1] / len);
-    fn[2] = (float)((double)fn[2] / len);
+    // FF.cpp:287-291: double len = sqrt(float); fn /= len in double, stored to float.  Numerator and denominator are
+    // float values, so each quotient is the correctly rounded fp32 divide (Figueroa, as above).
+    const float len = sqrtf(fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2]);
+    fn[0] = fn[0] / len;
+    fn[1] = fn[1] / len;
+    fn[2] = fn[2] / len;
     float fw[3];
     xform_dir(pose, fn, fw);
     e.px = fpx; e.py = fpy; e.pz = fpz;
@@ -453,7 +488,7 @@ DSM_HD FuseOutcome fuse_update(const FuseConst &c, int ref_idx, const float *pos
 DSM_HD bool seed_spawns(const SeedView &sd, bool fused) {
     if (sd.mean_depth == 0) return false;
     if (fused) return false;
-    if ((double)sd.view_cos < kAngleCos) return false;
+    if (sd.view_cos < flt_above(kAngleCos)) return false; // (double)view_cos < MAX_ANGLE_COS
     if (sd.nx == 0 && sd.ny == 0 && sd.nz == 0) return false;
     return true;
 }

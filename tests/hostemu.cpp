@@ -243,6 +243,7 @@ void fuse(Emu &e, int ref_idx, const float *pose, const float *inv, dsm_surfel *
     FuseConst fc;
     fc.k = e.K; fc.far_d = e.far_d; fc.near_d = e.near_d;
     fc.baseline = e.baseline; fc.disp_err = e.disp_err; fc.min_tol = e.min_tol; fc.w = e.w; fc.h = e.h;
+    fuse_const_prepare(fc);
     for (int i = 0; i < M; i++) {
         Surfel s;
         memcpy(&s, &local[i], sizeof s);
@@ -252,7 +253,8 @@ void fuse(Emu &e, int ref_idx, const float *pose, const float *inv, dsm_surfel *
         if (oc == kFuseNeedPixel) {
             const int sidx = e.label[e.key(ui, vi)];
             const SeedView none = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // label -1: the all-zero seed (k_fuse_surfels)
-            oc = fuse_update(fc, ref_idx, pose, s, pc, nc, e.D(ui, vi), sidx >= 0 ? view_of(e.seeds[sidx]) : none);
+            const SeedView sv = sidx >= 0 ? view_of(e.seeds[sidx]) : none;
+            oc = fuse_update(fc, ref_idx, pose, s, pc, nc, e.D(ui, vi), sv, depth_weight(sv.mean_depth));
             if (oc == kFuseFused) e.seeds[sidx].fused = 1;
         }
         if (oc == kFuseDeleted) local[i].update_times = 0;
@@ -381,6 +383,28 @@ int emu_newton_step_mismatches(const float *a, const int *n_core, int n) {
         for (int k = 0; k < n_core[i]; k++) b += 2; // as the reference accumulates it
         const float ref = (float)((double)(-a[i]) / ((double)b + 10.0)), got = huber_newton_step(a[i], b);
         bad += memcmp(&ref, &got, 4) != 0 && !(ref != ref && got != got);
+    }
+    return bad;
+}
+// the association's depth tolerance (dsm_math.h, fuse_depth_tolerance) vs the reference's double expression
+// (FF.cpp:250-253), and the normal's renormalisation as fp32 divides vs FF.cpp:287-291
+int emu_fuse_fp32_mismatches(const float *z, const float *a, const float *b, int n, int rgbd, float focal, int *used_fp32) {
+    FuseConst c;
+    c.k.fx = focal; c.k.fy = focal; c.k.cx = 0; c.k.cy = 0;
+    c.far_d = 30.0f; c.near_d = 0.5f; c.w = c.h = 0;
+    if (rgbd) { c.baseline = 0.08; c.disp_err = 1.0; c.min_tol = 0.05; }
+    else { c.baseline = 0.5; c.disp_err = 4.0; c.min_tol = 0.1; }
+    fuse_const_prepare(c);
+    *used_fp32 = c.tol32 ? 1 : 0;
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const float cam_f = camera_focal(c.k);
+        float tol = (float)((double)(z[i] * z[i]) / (c.baseline * (double)cam_f) * c.disp_err);
+        tol = (float)((double)tol < c.min_tol ? c.min_tol : (double)tol);
+        const float got = fuse_depth_tolerance(c, z[i]);
+        bad += memcmp(&tol, &got, 4) != 0 && !(tol != tol && got != got);
+        const float q_ref = (float)((double)a[i] / (double)b[i]), q = a[i] / b[i];
+        bad += memcmp(&q_ref, &q, 4) != 0 && !(q_ref != q_ref && q != q);
     }
     return bad;
 }

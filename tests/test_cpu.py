@@ -234,6 +234,26 @@ def test_double_typed_compares_in_fp32(hostemu_lib):
     assert emu.emu_newton_step_mismatches(a.ctypes.data, n_core.ctypes.data, len(a)) == 0
 
 
+def test_fuse_expressions_in_fp32(hostemu_lib):
+    """k_fuse_surfels evaluates the depth tolerance and the renormalisation of the fused normal in fp32 where the
+    reference's double expressions allow it exactly (dsm_math.h): equal bits on depths across and beyond the working
+    range, for both constant sets and several focal lengths; a focal length for which BASELINE * f is no float falls
+    back to the double form (and is equal trivially)."""
+    emu = C.CDLL(hostemu_lib)
+    emu.emu_fuse_fp32_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(21)
+    n = 2_000_000
+    z = np.concatenate([rng.uniform(0.5, 30.0, n), rng.uniform(1e-3, 200.0, n // 4), 10.0 ** rng.uniform(-3, 3, n // 4)]).astype(np.float32)
+    bits = rng.integers(0, 2 ** 32, len(z), dtype=np.uint64).astype(np.uint32)
+    a = np.ascontiguousarray(bits.view(np.float32))
+    b = np.ascontiguousarray(np.concatenate([rng.uniform(1e-3, 4.0, len(z) // 2), 10.0 ** rng.uniform(-30, 30, len(z) - len(z) // 2)]).astype(np.float32))
+    z = np.ascontiguousarray(z)
+    for rgbd, focal, expect_fp32 in ((0, 707.0912, 1), (0, 718.856, 1), (0, 1400.0, 1), (1, 525.0, 1), (1, 517.3, 0), (0, 0.3337, 1)):
+        used = C.c_int(-1)
+        assert emu.emu_fuse_fp32_mismatches(z.ctypes.data, a.ctypes.data, b.ctypes.data, len(z), rgbd, focal, C.byref(used)) == 0, (rgbd, focal)
+        assert used.value == expect_fp32, (rgbd, focal, used.value)
+
+
 def test_stable_skip_fixed_point_bruteforce():
     """The tmin fixed point of k_assign/k_resolve/k_apply vs the reference's sequential scan
     (FF.cpp:400,445,450) on random (old label, pick, stable) instances."""
