@@ -78,6 +78,40 @@ def pmc_traffic(stage, name="r02_pmc_traffic.json"):
     return None, None
 
 
+def valu_issue(fps_per_gpu):
+    """The roof that does bind this path: VALU instruction issue.  Wave-instructions per frame from the committed
+    rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r02_pmc_sq_batch8.md; the
+    counts are per launch, a frame launches k_assign / k_update_seeds / k_commit_seeds three times and k_resolve twice)
+    against what 1 024 SIMDs issue at one wave64 instruction per 4 cycles and 2.4 GHz.  None when no pass is on file."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_sq_batch8.md")
+    if not os.path.exists(path):
+        return None
+    per_launch = {}
+    col = None
+    for line in open(path):
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        if col is None:
+            if "SQ_INSTS_VALU" in cells:
+                col = cells.index("SQ_INSTS_VALU")
+            continue
+        if "dsm::k_" in cells[0] and col < len(cells):
+            name = cells[0].split("dsm::", 1)[1].split("(")[0]
+            try:
+                per_launch[name] = float(cells[col])
+            except ValueError:
+                pass
+    if not per_launch:
+        return None
+    launches = {"k_assign<false, true>": 2, "k_update_seeds<true, true>": 2, "k_commit_seeds<true>": 3, "k_resolve<true>": 2}
+    per_frame = sum(v * launches.get(k, 1) for k, v in per_launch.items() if not k.startswith("k_repack")) / 8.0
+    peak = 256 * 4 * 2.4e9 / 4.0
+    return {"valu_wave_insts_per_frame": round(per_frame), "peak_wave_insts_per_s": peak,
+            "frames_per_s_at_peak": round(peak / per_frame, 1), "frac": round(fps_per_gpu * per_frame / peak, 4),
+            "source": "profiles/r02_pmc_sq_batch8.md (rocprofv3 --pmc SQ_INSTS_VALU, launches batched over 8 subsequences)",
+            "note": "every instruction priced at the fp32 rate; the float<->double conversions of the mixed-precision "
+                    "expressions issue at a quarter of it (profiles/r02_issue_rates.md)"}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -580,6 +614,8 @@ def main():
     b_alg_frame = 9 * n_pix + 60 * n_seed + 88 * m_avg + 44 * k_avg
     out["e2e_algorithmic_GBps"] = round(fps * b_alg_frame / 1e9, 2)
     out["e2e_hbm_frac"] = round(fps * b_alg_frame / 1e9 / (HBM_PEAK_GBS * world), 5)
+    if args.mode == "batched":
+        out["valu_issue"] = valu_issue(fps / world)
 
     if rank == 0:
         print(json.dumps(out))
