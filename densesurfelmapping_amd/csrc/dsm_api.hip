@@ -632,6 +632,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     c.w = w; c.h = hh;
     c.pitch = (w + 63) / 64 * 64;
     c.gw = w / kCell; c.gh = hh / kCell; // FF.cpp:14-15
+    c.gw_magic = c.gw > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c.gw) + 1u : 0u; // (gw == 1: seed_cell special-cases it)
     c.n_seed = c.gw * c.gh;
     c.k.fx = cfg->fx; c.k.fy = cfg->fy; c.k.cx = cfg->cx; c.k.cy = cfg->cy;
     c.far_d = cfg->far_dist; c.near_d = cfg->near_dist;

@@ -47,6 +47,7 @@ struct DeviceCtx {
     // geometry
     int32_t w, h, pitch; // pitch = row stride in elements of every image-shaped plane (multiple of 64)
     int32_t gw, gh, n_seed;
+    uint32_t gw_magic; // floor(2^32 / gw) + 1: s / gw == mulhi(s, gw_magic) for every seed index s < 65 536 (seed_cell)
     Intrinsics k;
     float far_d, near_d;
     double huber, baseline, disp_err, min_tol;

@@ -219,6 +219,22 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     return o;
 }
 
+// Element at a 32-bit BYTE offset from a wave-uniform base: compiles to global_load v, v_off, s[base] -- the offset is the
+// vector address.  Indexing with an int (p[y * pitch + x]) costs a sign extension, a 64-bit shift and a 64-bit add in
+// the vector ALU per access, and a 64-bit multiply-add where the index is formed; the per-seed kernels make a dozen
+// such accesses per lane and are bound by instruction issue.
+template <typename T> __device__ __forceinline__ T ld_off(const T *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ void st_off(T *base, unsigned byte_off, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+// grid cell of seed s (s < 65 536: dsm_create): the quotient by multiplication with the reciprocal the host rounded up
+__device__ __forceinline__ void seed_cell(const DeviceCtx *c, int s, int &gx, int &gy) {
+    gy = c->gw > 1 ? (int)__umulhi((unsigned)s, c->gw_magic) : s;
+    gx = s - (int)__umul24((unsigned)gy, (unsigned)c->gw);
+}
+
 __device__ __forceinline__ const FrameParams &frame_params(const DeviceCtx *c) { return c->cur->p; }
 __device__ __forceinline__ const uint8_t *frame_image(const DeviceCtx *c, const FrameParams &) { return as_global(c->cur->img); }
 __device__ __forceinline__ const float *frame_depth(const DeviceCtx *c, const FrameParams &) { return as_global(c->cur->dep); }
@@ -358,11 +374,12 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
         // reads or writes these pixels: every seed window ends before them)
         if (FIRST) c->label[y * pitch + x] = c->label_alt[y * pitch + x] = -1;
     } else if (x < w && y < h) {
-        const int p = y * pitch + x;
-        const float pix_i = (float)img[p];
-        const float pix_d = dep[p];
+        const int p = __mul24(y, pitch) + x;
+        const unsigned p4 = (unsigned)p << 2; // byte offset into the 4-byte planes, see ld_off
+        const float pix_i = (float)ld_off(img, (unsigned)p);
+        const float pix_d = ld_off(dep, p4);
         int l = 0;
-        if (!FIRST) l = label_in[p];
+        if (!FIRST) l = ld_off(label_in, p4);
         const int pick = pick_seed(x, y, pix_i, pix_d, gw, gh,
                                    [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
                                        const int li = (gy - cy0) * kTileCellsX + (gx - cx0);
@@ -373,12 +390,12 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
                                    });
         if (pick < 0) { // every candidate cost >= the reference's 1e6 sentinel: it would index seeds[-1]
             atomicOr(c->status, kStatusBadPick);
-            if (FIRST) c->label[p] = 0; else c->cand[p] = l;
+            if (FIRST) st_off(c->label, p4, 0); else st_off(c->cand, p4, l);
         } else if (FIRST) {
-            c->label[p] = pick;
+            st_off(c->label, p4, pick);
         } else {
-            c->cand[p] = pick;
-            const int tl = c->tmin[l]; // -1 never changes; >= 0 only moves among values >= 0
+            st_off(c->cand, p4, pick);
+            const int tl = ld_off(c->tmin, (unsigned)l << 2); // -1 never changes; >= 0 only moves among values >= 0
             if (tl == -1) {
                 // the old seed was unstable at sweep start: this pixel is evaluated whatever happens
                 // elsewhere, so its pick loses `stable` no later than at p
@@ -522,7 +539,8 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = seed_of_block(blk.x, wv, c->gw, c->gh);
+    // (one seed per wave: the index lives in a scalar register, and so does every address formed from it)
+    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh));
     if (s < 0) return;
     stamp(c, sweep, s, 0, lane);
     const FrameParams &fp = frame_params(c);
@@ -531,7 +549,8 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
     const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
     int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
     const int w = c->w, h = c->h, pitch = c->pitch;
-    const int gx = s % c->gw, gy = s / c->gw;
+    int gx, gy;
+    seed_cell(c, s, gx, gy);
     const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
     const int t_self = c->tmin[s];
     const float4 old = c->core[s]; // needed only after the sums: issued with the window loads, not behind them
@@ -541,35 +560,40 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
     int lab[4], pi[4], cd[4], pk[4];
     float pd[4];
     bool pimg[4];
+    // pixel key of this lane's first window pixel; the other three are 4, 8, 12 rows further down (keys are
+    // non-negative wherever they are used: a pixel outside the image reads pixel 0 and is masked out)
+    const int x = wx0 + (lane & (kWin - 1)), y0 = wy0 + (lane >> 4);
+    const bool x_in = x >= 0 && x < w;
+    const int key0 = __mul24(y0, pitch) + x, row4 = 4 * pitch;
 #pragma unroll
     for (int k = 0; k < 4; k++) { // independent loads, one round trip
-        const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        pimg[k] = x >= 0 && x < w && y >= 0 && y < h;
-        pk[k] = pimg[k] ? y * pitch + x : 0;
-        lab[k] = label_in[pk[k]];
-        if (APPLY) cd[k] = c->cand[pk[k]];
-        pd[k] = dep[pk[k]];
-        pi[k] = (int)img[pk[k]];
+        const int y = y0 + 4 * k;
+        pimg[k] = x_in && y >= 0 && y < h;
+        pk[k] = pimg[k] ? key0 + k * row4 : 0;
+        const unsigned o4 = (unsigned)pk[k] << 2;
+        lab[k] = ld_off(label_in, o4);
+        if (APPLY) cd[k] = ld_off(c->cand, o4);
+        pd[k] = ld_off(dep, o4);
+        pi[k] = (int)ld_off(img, (unsigned)pk[k]);
     }
     if (APPLY) {
         int tl[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) tl[k] = c->tmin[lab[k]];
+        for (int k = 0; k < 4; k++) tl[k] = ld_off(c->tmin, (unsigned)lab[k] << 2);
+        const bool own_x = ((x >> 3) < c->gw ? (x >> 3) : c->gw - 1) == gx;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int idx = k * 64 + lane;
-            const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+            const int y = y0 + 4 * k;
             if (tl[k] < pk[k]) lab[k] = cd[k];
-            const int ox = (x >> 3) < c->gw ? (x >> 3) : c->gw - 1, oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
-            if (pimg[k] && ox == gx && oy == gy) label_out[pk[k]] = lab[k];
+            const int oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
+            if (pimg[k] && own_x && oy == gy) st_off(label_out, (unsigned)pk[k] << 2, lab[k]);
         }
     }
     if (t_self == kIntMax) return; // stable: FF.cpp:479-480
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        const int y = y0 + 4 * k;
         // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
         const bool mem = pimg[k] && x < w - 1 && y < h - 1 && lab[k] == s;
         const float d = mem ? pd[k] : 0.0f;
@@ -735,7 +759,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = seed_of_block(blk.x, wv, c->gw, c->gh);
+    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh)); // scalar, see k_update_seeds
     if (s < 0) return;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
@@ -745,7 +769,9 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
     const double hr = c->huber;
     const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
     const float4 core = c->core[s];
-    const int wx0 = (s % c->gw) * kCell + kCell / 2 - kCell, wy0 = (s / c->gw) * kCell + kCell / 2 - kCell;
+    int gx, gy;
+    seed_cell(c, s, gx, gy);
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
     float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2];
     float *N0 = s_col[wv][3], *N1 = s_col[wv][4], *N2 = s_col[wv][5];
     float *ld = P0;
@@ -756,14 +782,16 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
     float far2 = 0.0f;
     int lab[4];
     float pd[4];
+    const int x0 = wx0 + (lane & (kWin - 1)), y0 = wy0 + (lane >> 4);
+    const int key0 = __mul24(y0, pitch) + x0, row4 = 4 * pitch; // pixel keys as byte offsets: see ld_off
 #pragma unroll
     for (int k = 0; k < 4; k++) { // 8 independent loads, one round trip
-        const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        const bool in = x >= 0 && x < w && y >= 0 && y < h;
-        const int p = in ? y * pitch + x : 0;
-        lab[k] = in ? c->label[p] : -1;
-        pd[k] = dep[p];
+        const int y = y0 + 4 * k;
+        const bool in = x0 >= 0 && x0 < w && y >= 0 && y < h;
+        const unsigned o4 = in ? (unsigned)(key0 + k * row4) << 2 : 0u;
+        const int l = ld_off(c->label, o4);
+        lab[k] = in ? l : -1;
+        pd[k] = ld_off(dep, o4);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -807,8 +835,9 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
                 x = xy & 0xffff; y = xy >> 16;
                 interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2; // FF.cpp:670-677
                 if (interior) { // neighbours for the forward differences, fetched before they are known to be needed
-                    d_right = dep[y * pitch + x + 1];
-                    d_down = dep[(y + 1) * pitch + x];
+                    const unsigned o4 = (unsigned)(__mul24(y, pitch) + x) << 2;
+                    d_right = ld_off(dep, o4 + 4u);
+                    d_down = ld_off(dep, o4 + ((unsigned)pitch << 2));
                 }
                 const float r = md - d;
                 ok = fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
@@ -1315,18 +1344,24 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
             float pc[3], nc[3];
             FuseOutcome oc = fuse_project(fc, ref_idx, inv, e, ui, vi, pc, nc);
             if (oc == kFuseNeedPixel) {
-                const int p = vi * c->pitch + ui;
-                const int sidx = c->label[p];
+                const unsigned p4 = (unsigned)(__mul24(vi, c->pitch) + ui) << 2; // byte offsets, see ld_off
+                const int sidx = ld_off(c->label, p4);
+                const float pix_depth = ld_off(dep, p4);
                 SeedView sd = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // label -1 (ragged border): the all-zero seed, see has_candidate_cell
                 float w1 = 0.0f;
                 if (sidx >= 0) {
-                    w1 = c->seed_weight[sidx];
-                    const dsm_seed *sp = &c->seeds[sidx];
-                    sd.size = sp->size; sd.nx = sp->norm_x; sd.ny = sp->norm_y; sd.nz = sp->norm_z;
-                    sd.px = sp->posi_x; sd.py = sp->posi_y; sd.pz = sp->posi_z;
-                    sd.view_cos = sp->view_cos; sd.mean_depth = sp->mean_depth; sd.mean_intensity = sp->mean_intensity;
+                    w1 = ld_off(c->seed_weight, (unsigned)sidx << 2);
+                    const float *sf = reinterpret_cast<const float *>(c->seeds);
+                    const unsigned so = __umul24((unsigned)sidx, (unsigned)sizeof(dsm_seed));
+                    static_assert(offsetof(dsm_seed, size) == 8 && offsetof(dsm_seed, norm_x) == 12 && offsetof(dsm_seed, posi_x) == 24 &&
+                                      offsetof(dsm_seed, view_cos) == 36 && offsetof(dsm_seed, mean_depth) == 40 &&
+                                      offsetof(dsm_seed, mean_intensity) == 44,
+                                  "Superpixel_seed layout (elements.h:5-20)");
+                    sd.size = ld_off(sf, so + 8); sd.nx = ld_off(sf, so + 12); sd.ny = ld_off(sf, so + 16); sd.nz = ld_off(sf, so + 20);
+                    sd.px = ld_off(sf, so + 24); sd.py = ld_off(sf, so + 28); sd.pz = ld_off(sf, so + 32);
+                    sd.view_cos = ld_off(sf, so + 36); sd.mean_depth = ld_off(sf, so + 40); sd.mean_intensity = ld_off(sf, so + 44);
                 }
-                oc = fuse_update(fc, ref_idx, pose, e, pc, nc, dep[p], sd, w1);
+                oc = fuse_update(fc, ref_idx, pose, e, pc, nc, pix_depth, sd, w1);
                 // the seed's `fused` mark: idempotent, but ~60 surfels fuse into a seed and a byte store into a line that
                 // thousands of lanes are writing is a read-modify-write in L2 -- look first (a stale 0 only repeats the store)
                 if (oc == kFuseFused && c->fused_flag[sidx] == 0) { c->seeds[sidx].fused = 1; c->fused_flag[sidx] = 1; }
