@@ -465,15 +465,16 @@ constexpr int kWin = 2 * kCell; // 16
 __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__ c, int sweep, int s, int lane, int wx0, int wy0,
                                                    const float4 old, float *dl, float *lt, int cnt, int sdx, int sdy, int si, int nd) {
     stamp(c, sweep, s, 2, lane);
-    cnt = wave_sum(cnt);
+    // integer sums (exact in the reference's fp32 accumulators), two per wave reduction: the member count (<= 256) above
+    // the intensity sum (<= 256 * 255 < 2^16), and the window offsets 12 bits each, shifted back by cnt * window origin
+    const int cnt_si = wave_sum(si | (cnt << 16));
+    cnt = cnt_si >> 16;
+    si = cnt_si & 0xffff;
     if (cnt == 0) { // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
         if (lane == 0) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(c->n_seed, s)], s);
         return;
     }
-    // integer sums (exact in the reference's fp32 accumulators): offsets within the window are summed
-    // 12 bits each in one word, then shifted back by cnt * window origin
     const int packed = wave_sum(sdx | (sdy << 16));
-    si = wave_sum(si);
     const int sx = (packed & 0xffff) + cnt * wx0, sy = (packed >> 16) + cnt * wy0;
     wave_lds_sync();
     const float fn = (float)cnt;
@@ -1108,10 +1109,12 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
             for (int q = 0; q < kFitSeeds; q++) {
                 const bool valid = lane < mg[q];
                 const float r = pq[q][0][0] * pn[q][0] + pq[q][0][1] * pn[q][1] + pq[q][0][2] * pn[q][2] + pn[q][3];
-                const int cls = huber_class32(r, hr_above);
-                // the residual column carries the tail sign for outliers (see fit_ordered_sum)
-                if (valid) s_col[q][3][lane] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
-                const unsigned long long mask = __ballot(valid && cls != 0);
+                // Huber class (huber_class32) as selects: the residual column carries r for a core element and the tail
+                // sign for an outlier, 0 for a NaN residual (see fit_ordered_sum)
+                const bool in_core = fabsf(r) < hr_above;
+                const float tail_v = r >= hr_above ? 1.0f : (r <= -hr_above ? -1.0f : 0.0f);
+                if (valid) s_col[q][3][lane] = in_core ? r : tail_v;
+                const unsigned long long mask = __ballot(valid && !in_core);
                 if (g == q) noncore[0] = mask;
             }
 #pragma unroll
@@ -1122,9 +1125,10 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
                         const int i = k * 64 + lane;
                         const bool valid = i < mg[q];
                         const float r = pq[q][k][0] * pn[q][0] + pq[q][k][1] * pn[q][1] + pq[q][k][2] * pn[q][2] + pn[q][3];
-                        const int cls = huber_class32(r, hr_above);
-                        if (valid) s_col[q][3][i] = cls == 0 ? r : cls == 1 ? 1.0f : cls == 2 ? -1.0f : 0.0f;
-                        const unsigned long long mask = __ballot(valid && cls != 0);
+                        const bool in_core = fabsf(r) < hr_above;
+                        const float tail_v = r >= hr_above ? 1.0f : (r <= -hr_above ? -1.0f : 0.0f);
+                        if (valid) s_col[q][3][i] = in_core ? r : tail_v;
+                        const unsigned long long mask = __ballot(valid && !in_core);
                         if (g == q) noncore[k] = mask;
                     }
                 }
