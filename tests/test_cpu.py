@@ -335,6 +335,35 @@ def test_product_never_imports_oracle():
 
 
 # ------------------------------------------------------------------ multi-rank merge (gloo, 2 ranks)
+def test_bench_reads_the_committed_profiles():
+    """bench.py's `traffic` and `valu_issue` come from rocprofv3 --pmc passes committed under profiles/ (counters
+    cannot be read from inside the run): the files it names exist, parse, and hold the kernels it looks up; and the
+    kernel-trace summaries DESIGN.md cites are there."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    b, src = bench.pmc_traffic("k_update_seeds<true>")
+    assert src == "r02_pmc_traffic.json" and 4_000_000 < b < 40_000_000
+    b8, src8 = bench.pmc_traffic("k_update_seeds<true, true>", "r02_pmc_traffic_batched.json")
+    assert src8 == "r02_pmc_traffic_batched.json" and 8 * 4_000_000 < b8 < 8 * b, "batched launches fetch less per frame (one handle per XCD)"
+    v = bench.valu_issue(19000.0)
+    assert v and 15e6 < v["valu_wave_insts_per_frame"] < 40e6 and 0.3 < v["frac"] < 1.2
+    for name in ("r02_kernel_trace_batch8x1.md", "r02_kernel_trace_batch8x4_default.md", "r02_kernel_trace_streams1.md",
+                 "r02_pmc_sq_batch8.md", "r02_bench_default.json", "r02_relaxed_sums.md", "r02_issue_rates.md"):
+        assert os.path.getsize(os.path.join(ROOT, "profiles", name)) > 200, name
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(rec["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+
+
 def test_shard_subsequences():
     from densesurfelmapping_amd.replay import shard_subsequences
     sh = shard_subsequences(4541, 8)
