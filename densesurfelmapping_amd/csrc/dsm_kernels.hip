@@ -19,7 +19,11 @@
 //   k_mark_key / k_scan_marks / k_extract_marked   move_add_surfels removal, SM.cpp:1476-1497
 //
 // Build with -ffp-contract=off: results are required to match the CPU reference bit for bit.
-// The work is stencil / gather / ordered reduction -- HBM/L2 bound, no MFMA.
+// The work is stencil / gather / ordered reduction: no MFMA (nothing is a dense contraction).  The superpixel kernels
+// are bound by VALU instruction issue (mixed fp32 / fp64 scalar-style arithmetic in the reference's order), the
+// map-sized ones (k_fuse_surfels, k_warp) by HBM.  Every frame kernel exists twice: for one handle (context in the
+// kernel arguments) and, BATCH, for several handles advancing in lockstep (context array, handle = low bits of the
+// dispatch index: one handle per XCD) -- see DESIGN.md section 4.
 #include "dsm_device.h"
 
 namespace dsm {
