@@ -128,8 +128,13 @@ struct dsm_handle {
         hipGraphExec_t g_sp = nullptr, g_map[2] = {nullptr, nullptr}, g_all[2] = {nullptr, nullptr};
         hipGraphExec_t g_sp_main = nullptr; // superpixel stages on the map stream (drop-in calls)
         hipEvent_t ev_sp = nullptr, ev_map = nullptr;
-    } pipe[8];
+    } pipe[16];
     int n_pipe = 1;
+    // frame groups (pipeline_depth >= 4): the superpixel stages of n_pipe / 2 consecutive frames as ONE batched launch
+    // per kernel over that half of the pipelines (submit_group)
+    DeviceCtx *d_pipe_ctxs = nullptr;                 // [n_pipe] the pipelines' contexts, for the batched kernels
+    hipGraphExec_t g_group[4] = {nullptr, nullptr, nullptr, nullptr}; // superpixel stages of pipelines [kG, (k+1)G)
+    hipGraphExec_t g_group_map[4] = {nullptr, nullptr, nullptr, nullptr}; // their fuse + tail stages, frame after frame
     unsigned params_pending = 0; // bit p: pipeline p has not yet waited for the latest params upload
     hipStream_t copy_stream = nullptr; // per-frame params go up here, so that they never queue behind the map stream
     hipEvent_t ev_params = nullptr;
@@ -343,14 +348,79 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
     return DSM_OK;
 }
 
+// Frame groups.  The superpixel stages of a frame need nothing but the frame, so those of G consecutive frames -- which
+// live on G different pipelines -- are launched as ONE batch (every kernel once for the G frames, grid z = pipeline: the
+// batched instantiations of dsm_kernels.hip), on the stream of the group's first pipeline; fuse + tail of the G frames
+// then follow on the map stream in frame order.  The pipelines form two groups (four from depth 16 on) used in turn,
+// so the batches of the next group(s) run while the map stream works the previous one off.  Same results as frame by
+// frame; the params of the G frames must have been staged, and frames_submitted be a multiple of G.
+int group_size(const dsm_handle *h) { return h->n_pipe >= 16 ? h->n_pipe / 4 : h->n_pipe / 2; }
+bool group_path(const dsm_handle *h) {
+    return h->n_pipe >= 4 && h->d_pipe_ctxs && !(h->cfg.flags & DSM_FLAG_NO_GRAPH);
+}
+int submit_group(dsm_handle *h) {
+    h->shadow_n = -1;
+    const int G = group_size(h);
+    const int p0 = (int)(h->frames_submitted % h->n_pipe); // a multiple of G
+    const int half = p0 / G;
+    // group k runs on the stream of pipeline k: HIP spreads streams over its four hardware queues in creation order, and
+    // the groups' first pipelines (0, G, 2G ...) would all sit on one queue -- their batches would run one after another
+    dsm_handle::Pipe &lead = h->pipe[half];
+    // the group's buffers are free once the map stream has finished the frames that used them last (it is in order:
+    // the last pipeline's event covers the others), and the frames' params must have landed
+    HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->pipe[p0 + G - 1].ev_map, 0));
+    const unsigned mask = ((1u << G) - 1u) << p0;
+    if (h->params_pending & mask) {
+        HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->ev_params, 0));
+        h->params_pending &= ~mask;
+    }
+    if (!h->g_group[half]) {
+        hipGraph_t g = nullptr;
+        HIP_TRY(h, hipStreamBeginCapture(lead.stream, hipStreamCaptureModeThreadLocal));
+        const hipError_t le = launch_frame(lead.ctx, fuse_grid_bound(h), true, lead.stream, nullptr, 0, kLastSuperpixelStage,
+                                           h->d_pipe_ctxs + p0, G);
+        const hipError_t ce = hipStreamEndCapture(lead.stream, &g);
+        if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
+        if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&h->g_group[half], g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+    }
+    HIP_TRY(h, hipGraphLaunch(h->g_group[half], lead.stream));
+    HIP_TRY(h, hipEventRecord(lead.ev_sp, lead.stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, lead.ev_sp, 0));
+    // fuse + tail of the G frames, in frame order, as one graph on the map stream (a graph launch per frame costs the
+    // map stream more than the two kernels do)
+    if (!h->g_group_map[half]) {
+        hipGraph_t g = nullptr;
+        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t le = hipSuccess;
+        for (int j = 0; j < G && le == hipSuccess; j++)
+            le = launch_frame(h->pipe[p0 + j].ctx, fuse_grid_bound(h), true, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
+        const hipError_t ce = hipStreamEndCapture(h->stream, &g);
+        if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
+        if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&h->g_group_map[half], g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+    }
+    HIP_TRY(h, hipGraphLaunch(h->g_group_map[half], h->stream));
+    for (int j = 0; j < G; j++) HIP_TRY(h, hipEventRecord(h->pipe[p0 + j].ev_map, h->stream));
+    h->hc = h->pipe[p0 + G - 1].ctx; // taps read the state of the latest frame
+    h->frames_submitted += G;
+    const int64_t up = (int64_t)h->map_upper + (int64_t)G * h->hc.n_seed;
+    h->map_upper = up > h->hc.cap ? h->hc.cap : (int)up;
+    return DSM_OK;
+}
+
 // run some or all stages of the next frame serially on the map stream (timed replays, state-level taps)
 int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, int hi) {
     h->shadow_n = -1;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
-    if (h->n_pipe > 1 && (h->params_pending & 0x100u)) {
+    if (h->n_pipe > 1 && (h->params_pending & 0x80000000u)) {
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
-        h->params_pending &= ~0x100u;
+        h->params_pending &= ~0x80000000u;
     }
     hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, ev, lo, hi);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -372,9 +442,9 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
 int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
-    if (h->n_pipe > 1 && (h->params_pending & 0x100u)) {
+    if (h->n_pipe > 1 && (h->params_pending & 0x80000000u)) {
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
-        h->params_pending &= ~0x100u;
+        h->params_pending &= ~0x80000000u;
     }
     const int lo = map_part ? kLastSuperpixelStage + 1 : 0, hi = map_part ? kNumStages - 1 : kLastSuperpixelStage;
     if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
@@ -666,7 +736,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &h->d_stage_depth, (size_t)w * hh));
     // per-pipeline superpixel state
     int np = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
-    if (np != 1 && np != 2 && np != 4 && np != 8) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4 or 8"); return bail(DSM_E_INVALID); }
+    if (np != 1 && np != 2 && np != 4 && np != 8 && np != 16) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4, 8 or 16"); return bail(DSM_E_INVALID); }
     h->n_pipe = np;
     if (np > 1) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
@@ -715,6 +785,13 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         if (np > 1) CREATE_TRY(hipEventRecord(pp.ev_map, h->stream)); // "buffers free"
     }
     h->hc = h->pipe[0].ctx;
+    if (np >= 4) {
+        CREATE_TRY(dev_alloc(h, &h->d_pipe_ctxs, (size_t)np));
+        DeviceCtx tmp[16];
+        for (int p = 0; p < np; p++) tmp[p] = h->pipe[p].ctx;
+        CREATE_TRY(hipMemcpyAsync(h->d_pipe_ctxs, tmp, sizeof(DeviceCtx) * (size_t)np, hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream)); // tmp is on the stack
+    }
     CREATE_TRY(hipHostMalloc((void **)&h->h_params, sizeof(FrameParams) * kParamRing, hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 256, hipHostMallocDefault));
     memset(h->h_scalars, 0, 256);
@@ -731,7 +808,11 @@ void dsm_destroy(dsm_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int p = 0; p < 8; p++) {
+    for (int i = 0; i < 4; i++) {
+        if (h->g_group[i]) (void)hipGraphExecDestroy(h->g_group[i]);
+        if (h->g_group_map[i]) (void)hipGraphExecDestroy(h->g_group_map[i]);
+    }
+    for (int p = 0; p < 16; p++) {
         dsm_handle::Pipe &pp = h->pipe[p];
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
         if (pp.g_sp) (void)hipGraphExecDestroy(pp.g_sp);
@@ -1145,8 +1226,16 @@ int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int
     for (int i = 0; i < n;) {
         int m = 0;
         if ((rc = stage_params_batch(h, n - i, slots + i, ref_idx + i, poses16 + 16 * (size_t)i, &m))) return rc;
-        for (int j = 0; j < m; j++)
-            if ((rc = submit_frame(h, true))) return rc;
+        for (int j = 0; j < m;) {
+            const int G = group_size(h);
+            if (group_path(h) && m - j >= G && h->frames_submitted % G == 0) {
+                if ((rc = submit_group(h))) return rc;
+                j += G;
+            } else {
+                if ((rc = submit_frame(h, true))) return rc;
+                j++;
+            }
+        }
         i += m;
     }
     if (n) h->fence_pending = true;

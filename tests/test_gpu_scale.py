@@ -69,18 +69,23 @@ def test_long_sequence_kitti_golden(mods, gold):
             assert map_sha(ff.map_download(), api.SURFEL_DTYPE) == case["map_sha256"][str(t + 1)], f"map after frame {t}"
     ff.close()
 
-    ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20)  # default pipeline depth
-    for t in range(period):
-        ff.frame_upload(t, frames[t][1], frames[t][2])
-    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
-    step = case["checkpoint_every"]
-    for base in range(0, case["frames"], step):
-        chunk = frames[base:base + step]
-        ff.replay_enqueue(*ff.pack_replay([f[0] % period for f in chunk], [f[4] for f in chunk], [f[3] for f in chunk]))
-        got = ff.map_download()
-        assert len(got) == per[base + step - 1]["n_local"]
-        assert map_sha(got, api.SURFEL_DTYPE) == case["map_sha256"][str(base + step)], f"pipelined replay, frames {base}..{base + step - 1}"
-    ff.close()
+    # default pipeline depth (4: the superpixel stages of two consecutive frames per batched launch), then 16 (eight per
+    # launch; the 50-frame chunks leave ragged ends that go frame by frame)
+    for depth in (0, 16):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20, pipeline_depth=depth)
+        for t in range(period):
+            ff.frame_upload(t, frames[t][1], frames[t][2])
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        step = case["checkpoint_every"]
+        for base in range(0, case["frames"], step):
+            chunk = frames[base:base + step]
+            ff.replay_enqueue(*ff.pack_replay([f[0] % period for f in chunk], [f[4] for f in chunk], [f[3] for f in chunk]))
+            got = ff.map_download()
+            assert len(got) == per[base + step - 1]["n_local"]
+            assert map_sha(got, api.SURFEL_DTYPE) == case["map_sha256"][str(base + step)], \
+                f"pipelined replay (depth {depth}), frames {base}..{base + step - 1}"
+        assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == per[-1]["labels_sha256"]
+        ff.close()
 
 
 def test_long_sequence_kitti_golden_batched(mods, gold):
