@@ -182,6 +182,27 @@ def event_timer(torch, ff):
     return timed
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: check that N devices are visible and re-run this command under
+    torch.distributed.run, one rank per GPU (RCCL rendezvous on 127.0.0.1).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    one_device = os.environ.get("DSM_BENCH_ONE_DEVICE", "0") == "1"
+    import torch
+    seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not one_device and seen < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this box shows {seen}; nothing was measured", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,8 +226,16 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs beside the headline (drop-in, configs 4 and 5, node)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # one rank per GPU under torch.distributed.run; this process only waits
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}), or let "
+                 f"`python bench.py --gpus {args.gpus}` launch them")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     B, K, W, F = args.streams or (32 if args.mode == "batched" else 8), args.steps, args.warmup, args.frames_per_step
     period = 50
@@ -252,7 +281,10 @@ def main():
         else:
             dist.init_process_group(backend)
     coll_dev = f"cuda:{device}" if backend == "nccl" else "cpu"
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world > 1:
+        if not one_device and torch.cuda.device_count() < world:
+            sys.exit(f"bench.py: rank {rank} sees {torch.cuda.device_count()} GPUs for a world of {world}")
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
 
     total = (W + K) * F
     lo_t, hi_t = W * F, total  # frame indices of the timed region, per subsequence
@@ -326,7 +358,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rank_fps = [B * K * F / dt]
     if world > 1:
+        mine = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_fps = [B * K * F / float(t.item()) for t in every]  # each rank's own rate between the two barriers
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -341,7 +378,13 @@ def main():
             buf = torch.empty(m * 44, dtype=torch.uint8, device=f"cuda:{device}")
             ff.map_copy_to_device(buf.data_ptr(), m)
             clouds.append(buf)
-        merged, counts = merge_clouds(torch.cat(clouds).to(coll_dev))
+        mine = torch.cat(clouds).to(coll_dev)
+        merge_clouds(mine[:44])  # communicator warm-up (first-collective setup is not the merge)
+        torch.cuda.synchronize()
+        t_m = time.perf_counter()
+        merged, counts = merge_clouds(mine)
+        torch.cuda.synchronize()
+        merge_s = time.perf_counter() - t_m
         merged_total = int(sum(counts))
 
     for bt in batches:
@@ -372,6 +415,14 @@ def main():
                    "mean_live_surfels": round(m_avg), "final_surfels_all_ranks": merged_total,
                    "parallelism": f"{world} GPU x {B} independent subsequences, all-gather of final cloud only"},
     }
+    if world > 1:
+        out["multi_gpu"] = {"world_size_seen_by_backend": dist.get_world_size(), "backend": dist.get_backend(),
+                            "per_rank_frames_per_s": [round(v, 1) for v in rank_fps],
+                            "min_rank_frames_per_s": round(min(rank_fps), 1), "max_rank_frames_per_s": round(max(rank_fps), 1),
+                            "final_cloud_all_gather_ms": round(merge_s * 1e3, 3),
+                            "final_cloud_bytes_all_ranks": int(merged_total) * 44,
+                            "note": "value = frames of all ranks / the slowest rank's time between the barriers; the all-gather of "
+                                    "the final clouds (counts, then the padded clouds) is outside the timed region"}
 
     k_avg = None
     if rank == 0 and not args.no_roofline:

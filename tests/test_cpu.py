@@ -782,3 +782,21 @@ def test_port_oracle_matches_long_golden(ob, synth):
             after, k = ob.PortOracle(cam).fuse_map(ref, img, dep, pose, m)
             assert (k, len(after)) == (want["n_new"], want["n_local"]), (key, trial)
             assert _map_sha(after, ob.SURFEL_DTYPE) == want["map_sha256"], (key, trial)
+
+
+def test_bench_gpus_flag_fails_loudly_without_devices():
+    """`python bench.py --gpus 2` where two GPUs are not visible (this container: none) exits non-zero and prints no result
+    line -- round 2's bench ran ONE rank and reported n_gpus 1 (missing #1)."""
+    import subprocess
+    import sys
+    try:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+            pytest.skip("two GPUs visible: covered by the gpu tests")
+    except ImportError:
+        pytest.skip("no torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSM_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible GPUs" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -810,19 +810,61 @@ def test_message_log_replay_driver(mods, tmp_path):
         assert node_state.file_digest(path)["sha256"] == gold["files"][kind]["sha256"], kind
 
 
+def _bench_line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
-    sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL)."""
+    sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL).  Launched the way a
+    user would: `python bench.py --gpus 2` starts its own ranks."""
     import subprocess
     import sys
-    env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+    env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "20", "--warmup", "5", "--streams", "2", "--frames-per-step", "4"],
                        env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    out = _bench_line(r)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["final_surfels_all_ranks"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N=1 only
+    mg = out["multi_gpu"]
+    assert mg["world_size_seen_by_backend"] == 2 and len(mg["per_rank_frames_per_s"]) == 2
+    assert mg["min_rank_frames_per_s"] <= mg["max_rank_frames_per_s"] and mg["final_cloud_all_gather_ms"] > 0
+    # value is the whole job over the slowest rank's time: never more than the sum of the ranks' own rates
+    assert out["value"] <= sum(mg["per_rank_frames_per_s"]) * 1.001
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` on a box with fewer than N devices must fail loudly -- not run one GPU and print n_gpus 1."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSM_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines()), r.stdout[-500:]
+    assert "visible GPUs" in r.stderr
+    # ... and a launcher-provided world that disagrees with --gpus is refused as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_two_gpus_rccl():
+    """The real thing where two devices exist: two ranks, one GPU each, RCCL all-gather of the final clouds."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSM_BENCH_ONE_DEVICE", "DSM_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--streams", "8",
+                        "--batches", "1", "--frames-per-step", "8", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    out = _bench_line(r)
+    assert out["n_gpus"] == 2 and out["multi_gpu"]["backend"] == "nccl" and out["multi_gpu"]["world_size_seen_by_backend"] == 2

@@ -181,6 +181,90 @@ def test_large_map_compaction_golden(mods, gold):
     ff.close()
 
 
+def test_batched_large_maps_headline_regime(mods, gold):
+    """The regime bench.py's headline runs in, oracle-checked: EIGHT handles in one batch, every one of them starting from
+    a map above 262 144 surfels -- k_frame_tail<BATCH> leaves its single-trip path (kTailFastWords) and k_fuse_surfels<BATCH>
+    runs its grid-stride loop -- with different stale fractions per handle, so that the K < k chains (SM.cpp:1104-1109),
+    K > k appends and the plain refill all occur inside ONE launch.  Frame 1: the 10 / 50 / 90 % stale maps against the
+    reference-TU digests, a nothing-stale map (K >= k) against the port oracle.  Then eight more frames, every handle
+    against the port oracle byte for byte.  Last, the same start through one handle's frame groups (pipeline depth 16)."""
+    api, synth, ob = mods
+    case = scale_cases.LARGE_MAP
+    rows = gold["large_map"]
+    cam = getattr(synth, case["camera"])
+    scene = synth.Scene(**case["scene"])
+    more = 8
+    frames = list(synth.sequence(cam, scene, case["base_frames"] + 1 + more))[case["base_frames"]:]
+    big, first = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, case)
+    assert first[0] == frames[0][0] and len(big) > 262144 + 8 * 7038
+    trials = list(case["trials"]) + [{"stale": 0.0, "dead": 0.0}]
+    which = [0, 1, 2, 3, 2, 1, 0, 3]
+    starts = [scale_cases.large_map_variant(big, t, synth) for t in trials]
+    slots, refs, poses = api.FusionFunctions.pack_replay(list(range(len(frames))), [f[4] for f in frames], [f[3] for f in frames])
+
+    def start_handle(depth):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=len(frames), surfel_capacity=len(big) + 16 * 7038 + 65536, pipeline_depth=depth)
+        for i, f in enumerate(frames):
+            ff.frame_upload(i, f[1], f[2])
+        return ff
+
+    handles = [start_handle(1) for _ in which]
+    for ff, w in zip(handles, which):
+        ff.map_upload(starts[w].astype(api.SURFEL_DTYPE))
+    batch = api.Batch(handles)
+    one = api.Batch.pack([(slots[:1], refs[:1], poses[:1])] * len(which))
+    batch.replay_enqueue(one[0], one[1], one[2], 1)
+    batch.synchronize()
+    # what the port oracle makes of every start map, frame by frame (it is what a failing digest is diffed against)
+    models = []
+    for w in range(len(trials)):
+        o, k = ob.PortOracle(cam).fuse_map(frames[0][4], frames[0][1], frames[0][2], frames[0][3], starts[w])
+        models.append(o)
+        if w < len(rows):
+            assert len(o) == rows[w]["n_local"] and map_sha(o, ob.SURFEL_DTYPE) == rows[w]["map_sha256"], "port oracle vs reference TU"
+    seen_less, seen_more = False, False
+    for b, (ff, w) in enumerate(zip(handles, which)):
+        got = ff.map_download()
+        assert len(got) > 262144
+        if w < len(rows):
+            assert ff.last_new_count() == rows[w]["n_new"] and len(got) == rows[w]["n_local"], (b, w)
+            assert map_sha(got, api.SURFEL_DTYPE) == rows[w]["map_sha256"], f"handle {b} (trial {trials[w]}): map differs from the reference TU's"
+            seen_less |= rows[w]["n_holes"] > rows[w]["n_new"]
+        else:
+            assert len(got) > len(starts[w]), "the nothing-stale start must take the K >= k branch"
+            seen_more = True
+        assert fields_equal(got, models[w].astype(api.SURFEL_DTYPE)) == [], (b, w)
+    assert seen_less and seen_more
+    # eight more frames in lockstep, checked after the 4th and the 8th
+    oracles = [ob.PortOracle(cam) for _ in trials]
+    done = 1
+    for chunk in (4, 4):
+        pk = api.Batch.pack([(slots[done:done + chunk], refs[done:done + chunk], poses[done:done + chunk])] * len(which))
+        batch.replay_enqueue(pk[0], pk[1], pk[2], chunk)
+        batch.synchronize()
+        for w in range(len(trials)):
+            for f in frames[done:done + chunk]:
+                models[w], _ = oracles[w].fuse_map(f[4], f[1], f[2], f[3], models[w])
+        done += chunk
+        for b, (ff, w) in enumerate(zip(handles, which)):
+            got = ff.map_download()
+            assert len(got) > 262144
+            assert fields_equal(got, models[w].astype(api.SURFEL_DTYPE)) == [], f"handle {b} after {done} frames"
+    for b, (ff, w) in enumerate(zip(handles, which)):
+        assert np.array_equal(ff.labels(), oracles[w].labels()), b
+    batch.close()
+    for ff in handles:
+        ff.close()
+    # frame groups: one handle, depth 16 (four frames per batched superpixel launch), the 50 % stale start
+    ff = start_handle(16)
+    ff.map_upload(starts[1].astype(api.SURFEL_DTYPE))
+    ff.replay_enqueue(slots[:1 + more], refs[:1 + more], poses[:1 + more])
+    got = ff.map_download()
+    assert len(got) > 262144
+    assert fields_equal(got, models[1].astype(api.SURFEL_DTYPE)) == [], "frame groups on a large map"
+    ff.close()
+
+
 def _random_rigid(rng, scale=0.05):
     a = rng.normal(size=3) * scale
     th = np.linalg.norm(a)
