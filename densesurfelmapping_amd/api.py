@@ -37,6 +37,7 @@ assert SURFEL_DTYPE.itemsize == 44 and SEED_DTYPE.itemsize == 60
 
 DSM_FLAG_NO_GRAPH = 1
 DSM_FLAG_UPLOAD_STREAM = 2
+DSM_FLAG_WAVE_STAMPS = 4
 DSM_MAX_STAGES = 32
 
 # every symbol include/dsm.h declares
@@ -52,7 +53,7 @@ ABI_SYMBOLS = (
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
     "dsm_batch_replay_timed",
-    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps",
+    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps", "dsm_debug_set_fit_small_cap",
     "dsm_debug_run_stages", "dsm_debug_get_label_buffer", "dsm_debug_set_label_buffer", "dsm_debug_get_seed_state",
     "dsm_debug_set_seed_state",
 )
@@ -132,6 +133,7 @@ def load_library():
     lib.dsm_get_seeds.argtypes = [_vp, _vp]
     lib.dsm_seed_count.argtypes = [_vp]
     lib.dsm_debug_wave_stamps.argtypes = [_vp, _vp]
+    lib.dsm_debug_set_fit_small_cap.argtypes = [_vp, C.c_int32]
     lib.dsm_debug_run_stages.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]
     lib.dsm_debug_get_label_buffer.argtypes = [_vp, C.c_int, _vp]
     lib.dsm_debug_set_label_buffer.argtypes = [_vp, C.c_int, _vp]
@@ -424,6 +426,9 @@ class FusionFunctions:
         core = np.ascontiguousarray(core, np.float32)
         stable = np.ascontiguousarray(stable, np.int32)
         self._check(self._lib.dsm_debug_set_seed_state(self._h, _ptr(core), _ptr(stable)))
+
+    def debug_set_fit_small_cap(self, cap):
+        self._check(self._lib.dsm_debug_set_fit_small_cap(self._h, int(cap)))
 
     def debug_wave_stamps(self) -> np.ndarray:
         out = np.zeros((5, self.n_seed, 8), np.int64)

@@ -369,6 +369,11 @@ int submit_group(dsm_handle *h) {
     // the group's buffers are free once the map stream has finished the frames that used them last (it is in order:
     // the last pipeline's event covers the others), and the frames' params must have landed
     HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->pipe[p0 + G - 1].ev_map, 0));
+    // Only the lead stream waits for the params upload, yet the bits of all G pipelines are cleared: the group's
+    // superpixel launch on `lead` is the only work that reads the params of these G frames before the map stream does,
+    // and the map stream waits for lead.ev_sp below.  A later submit_frame on one of these pipelines (ragged end of a
+    // replay) stages its own params first, which sets its bit again (stage_params: params_pending = ~0u) -- so a cleared
+    // bit never stands for an upload its stream has not been ordered behind.
     const unsigned mask = ((1u << G) - 1u) << p0;
     if (h->params_pending & mask) {
         HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->ev_params, 0));
@@ -550,6 +555,7 @@ int check_status(dsm_handle *h) {
     const int st = h->h_scalars[2];
     if (st) (void)hipMemsetAsync(h->hc.status, 0, 4, h->stream); // report once, then start clean
     if (st & kStatusCapacity) return fail(h, DSM_E_CAPACITY, "resident surfel capacity %d exceeded", h->hc.cap);
+    if (st & kStatusBadLabels) return fail(h, DSM_E_INVALID, "a superpixel had more member pixels than its 15x15 reach allows: the label image was not produced by the assignment stage (dsm_debug_set_label_buffer?)");
     if (st & kStatusBadPick) return fail(h, DSM_E_INVALID, "a pixel had no candidate superpixel below the reference's 1e6 cost sentinel (depth outside the sensor range?); the reference indexes seeds[-1] here");
     return DSM_OK;
 }
@@ -661,6 +667,13 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     // way, through reads and writes of superpixel_seeds[-1] that happen to be harmless (FF.cpp:442-451).
     if ((w / kCell) * (hh / kCell) > 64 * 1024) return fail(nullptr, DSM_E_INVALID, "more than 65536 superpixels");
     if (!(cfg->fx != 0) || !(cfg->fy != 0)) return fail(nullptr, DSM_E_INVALID, "zero focal length");
+    // the kernels compare floats against these double constants in fp32 (dsm_math.h, flt_above / flt_below): the
+    // neighbouring-float construction holds for positive normal thresholds only
+    if (!(cfg->huber_range >= 1e-30 && cfg->huber_range <= 1e30))
+        return fail(nullptr, DSM_E_INVALID, "huber_range %g must be a positive, finite threshold", cfg->huber_range);
+    if (!(cfg->min_tolerate_diff >= 1e-30 && cfg->min_tolerate_diff <= 1e30))
+        return fail(nullptr, DSM_E_INVALID, "min_tolerate_diff %g must be a positive, finite threshold", cfg->min_tolerate_diff);
+    if (!(cfg->baseline > 0) || !(cfg->disparity_error > 0)) return fail(nullptr, DSM_E_INVALID, "baseline and disparity_error must be positive");
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -774,13 +787,8 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &ps, 64));
         q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16; q.fit_big_count = ps + 24;
         q.fit_small_cap = kFitSmallCap;
-        if (const char *e = getenv("DSM_FIT_SMALL_CAP")) {
-            const int v = atoi(e);
-            if (v >= 0 && v < kFitSmallCap) q.fit_small_cap = v;
-        }
         CREATE_TRY(dev_alloc(h, &q.cur, 1));
-        if (const char *e = getenv("DSM_WAVE_STAMPS"))
-            if (e[0] == '1') CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));
+        if (cfg->flags & DSM_FLAG_WAVE_STAMPS) CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));
         q.params = h->d_params;
         if (np > 1) CREATE_TRY(hipEventRecord(pp.ev_map, h->stream)); // "buffers free"
     }
@@ -1345,10 +1353,29 @@ int dsm_debug_set_seed_state(dsm_handle *h, const float *core4, const int32_t *s
     return DSM_OK;
 }
 
-// debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_WAVE_STAMPS=1)
+// test knob: the longest list the short-column tier of k_seed_fit takes in batched launches (lets a test push ordinary
+// groups of seeds through the queue tier).  The contexts are baked into captured graphs and copied by dsm_batch_create,
+// so it must be called on a fresh handle: before the first frame and before the handle joins a batch.
+int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap) {
+    if (!h) return DSM_E_INVALID;
+    if (cap < 0 || cap > kFitSmallCap) return fail(h, DSM_E_INVALID, "fit_small_cap %d out of range [0, %d]", cap, kFitSmallCap);
+    if (h->frames_submitted != 0) return fail(h, DSM_E_STATE, "dsm_debug_set_fit_small_cap: the handle has already fused frames");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    for (int p = 0; p < h->n_pipe; p++) h->pipe[p].ctx.fit_small_cap = cap;
+    h->hc.fit_small_cap = cap;
+    if (h->d_pipe_ctxs) {
+        DeviceCtx tmp[16];
+        for (int p = 0; p < h->n_pipe; p++) tmp[p] = h->pipe[p].ctx;
+        HIP_TRY(h, hipMemcpy(h->d_pipe_ctxs, tmp, sizeof(DeviceCtx) * (size_t)h->n_pipe, hipMemcpyHostToDevice));
+    }
+    return DSM_OK;
+}
+
+// debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_FLAG_WAVE_STAMPS)
 int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
     if (!h || !out) return DSM_E_INVALID;
-    if (!h->hc.stamps) return fail(h, DSM_E_STATE, "handle was created without DSM_WAVE_STAMPS=1");
+    if (!h->hc.stamps) return fail(h, DSM_E_STATE, "handle was created without DSM_FLAG_WAVE_STAMPS");
     int rc = bind_device(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1389,6 +1416,17 @@ int bfail(dsm_batch *b, int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                     \
         if (e_ != hipSuccess) return bfail(b, DSM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
+
+// the handles of a batch advance their parameter rings together; one that was used alone for a while is out of step
+int batch_rings_in_step(dsm_batch *b) {
+    const int64_t r0 = b->hs[0]->frames_submitted % kParamRing;
+    for (size_t j = 1; j < b->hs.size(); j++)
+        if (b->hs[j]->frames_submitted % kParamRing != r0)
+            return bfail(b, DSM_E_STATE, "handle %zu has fused %lld frames, handle 0 %lld: the parameter rings of a batch must be in step "
+                         "(a handle was used alone for a different number of frames); nothing was enqueued", j,
+                         (long long)b->hs[j]->frames_submitted, (long long)b->hs[0]->frames_submitted);
+    return DSM_OK;
+}
 
 // params of frames [i0, i0+m) of every handle go up on the handles' own streams; the batch stream waits for them
 int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
@@ -1431,6 +1469,7 @@ int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
         const dsm_handle *h = handles[j];
         if (!h) return bfail(nullptr, DSM_E_INVALID, "null handle");
         if (h->n_pipe != 1) return bfail(nullptr, DSM_E_INVALID, "handles of a batch need pipeline_depth 1");
+        if (h->own_up_stream) return bfail(nullptr, DSM_E_INVALID, "handles of a batch must not use DSM_FLAG_UPLOAD_STREAM (a batch does not wait on a handle's upload stream)");
         if (h->device != handles[0]->device || h->hc.w != handles[0]->hc.w || h->hc.h != handles[0]->hc.h)
             return bfail(nullptr, DSM_E_INVALID, "handles of a batch must share device and image size");
         if (h->frames_submitted % kParamRing != handles[0]->frames_submitted % kParamRing)
@@ -1487,6 +1526,7 @@ int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slot
     if (!b) return DSM_E_INVALID;
     if (n_frames < 0 || (n_frames > 0 && (!slots || !ref_idx || !poses16))) return bfail(b, DSM_E_INVALID, "null/negative argument");
     BHIP_TRY(b, hipSetDevice(b->device));
+    if (int rc = batch_rings_in_step(b)) return rc;
     dsm_handle *h0 = b->hs[0];
     for (int i = 0; i < n_frames;) {
         int m = n_frames - i;
@@ -1528,6 +1568,7 @@ int dsm_batch_replay_timed(dsm_batch *b, int32_t n_frames, const int32_t *slots,
     if (!b || !out) return DSM_E_INVALID;
     if (n_frames < 0 || (n_frames > 0 && (!slots || !ref_idx || !poses16))) return bfail(b, DSM_E_INVALID, "null/negative argument");
     BHIP_TRY(b, hipSetDevice(b->device));
+    if (int rc = batch_rings_in_step(b)) return rc;
     out->n_stages = kNumStages;
     for (int s = 0; s < kNumStages; s++) out->name[s] = kStageNames[s];
     dsm_handle *h0 = b->hs[0];

@@ -71,7 +71,7 @@ struct DeviceCtx {
     int32_t *first_empty; // [kSweeps][kWorkers] first unstable seed without pixels, per worker chunk
     int32_t *worklist;    // pixel keys whose old and new seeds were both stable at sweep start
     int32_t *work_count;
-    int32_t fit_small_cap;  // kFitSmallCap, or less (DSM_FIT_SMALL_CAP: lets a test push ordinary groups through the other tier)
+    int32_t fit_small_cap;  // kFitSmallCap, or less (dsm_debug_set_fit_small_cap: lets a test push ordinary groups through the other tier)
     int32_t *fit_big_count; // groups of seeds queued in `worklist` for the full-length tier of k_seed_fit (batched launches)
     GnHeader *gn_hdr; // [S]
     float *gn_pts;    // [S][3][kGnCap]
@@ -101,12 +101,13 @@ struct DeviceCtx {
     int32_t cursor_mul, cursor_add;
     int32_t *status; // sticky device-side error bits
     FrameCur *cur; // device memory, see FrameCur
-    // optional per-wave phase stamps (shader clock) of the per-seed kernels; null unless DSM_WAVE_STAMPS=1
+    // optional per-wave phase stamps (shader clock) of the per-seed kernels; null unless DSM_FLAG_WAVE_STAMPS
     long long *stamps; // [5 kernels][n_seed][8]
 };
 
 constexpr int kStatusCapacity = 1;
 constexpr int kStatusBadPick = 2;
+constexpr int kStatusBadLabels = 4; // a superpixel with more members than its 15 x 15 reach (injected label image)
 
 // launch all kernels of one frame on `stream`.  with_compaction: SurfelMap::fuse_map semantics,
 // otherwise FusionFunctions::fuse_initialize_map.  If ev != nullptr, an event is recorded before

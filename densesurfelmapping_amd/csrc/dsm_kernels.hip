@@ -77,25 +77,7 @@ __device__ __forceinline__ Blk16 load_blk(const float *l) {
     const float4 c = *reinterpret_cast<const float4 *>(l + 8), d = *reinterpret_cast<const float4 *>(l + 12);
     return Blk16{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w}};
 }
-// DSM_RELAXED_SUMS (experiment, never the shipped build): the order-sensitive sums of the plane fit (k_seed_points'
-// six fp32 sums, k_seed_fit's fourteen double sums) as four interleaved partial sums instead of one serial chain --
-// what the reference's summation order costs, measured (tools/relaxed_check.py).  The superpixel sweeps
-// keep their exact order in every build: labels are bit-exact by contract.
-#ifndef DSM_RELAXED_SUMS
-#define DSM_RELAXED_SUMS 0
-#endif
-__device__ __forceinline__ float ordered_sum(const float *l, int n, bool may_relax = false) {
-#if DSM_RELAXED_SUMS
-    if (may_relax) {
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        for (int i = 0; i < n; i += kBlk) {
-            const Blk16 v = load_blk(l + i);
-#pragma unroll
-            for (int q = 0; q < kBlk; q += 4) { a0 += v.e[q]; a1 += v.e[q + 1]; a2 += v.e[q + 2]; a3 += v.e[q + 3]; }
-        }
-        return (a0 + a1) + (a2 + a3);
-    }
-#endif
+__device__ __forceinline__ float ordered_sum(const float *l, int n) {
     float a = 0.0f;
     for (int i = 0; i < n; i += kBlk) {
         const Blk16 v = load_blk(l + i);
@@ -120,55 +102,27 @@ __device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph
     if (c->stamps && lane == 0) c->stamps[((int64_t)kid * c->n_seed + s) * 8 + ph] = clock64();
 }
 
-// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.
-// The per-seed kernels read overlapping 16x16 windows, so neighbouring seeds should share an L2:
-// XCD k works on the k-th vertical strip of the seed grid, top to bottom (vertical strips rather than
-// bands of rows, because rows differ a lot in cost -- sky rows are empty -- and strips do not).
-// A block is 4 consecutive seeds of one row; returns the seed of wave `wv`, or -1 outside the grid.
-//
-// Measured on MI355X at 1226x370 (profiles/r01_xcd_mapping.md): strips cut the fabric reads of
-// k_seed_planes from 7.4 MB to 2.7 MB per launch (FETCH_SIZE) but the kernel got *slower* (41.5 -> 48.5
-// us, and bands of rows 44.7 us) and 8-stream throughput fell 14.5k -> 13.1k frames/s: the path is bound by
-// dependent-operation latency, not by fabric bytes, and the plain round-robin order spreads the expensive
-// seeds best.  The plain order is therefore the default; -DDSM_XCD_STRIPS=1 selects the strips.
-#ifndef DSM_XCD_STRIPS
-#define DSM_XCD_STRIPS 0
-#endif
-#ifndef DSM_TILED_UPDATE
-#define DSM_TILED_UPDATE 0 // experiment: k_update_seeds with its windows staged through a 24x24 LDS tile per 2x2 seeds
-#endif
-__device__ __forceinline__ int strip_blocks_per_row(int gw) { return (((gw + 3) >> 2) + 7) >> 3; }
+// A block of the wave-per-seed kernels is 4 consecutive seeds; returns the seed of wave `wv`, or -1 outside the grid.
+// Bottom rows first: in driving scenes they are the expensive seeds (near ground, every pixel has depth, long lists),
+// the top rows are sky and leave after the gather.  Workgroups are dispatched in index order and the grid does not fit
+// the machine at once, so what is dispatched last must be what finishes fastest.  (An XCD-local order -- vertical
+// strips of the seed grid per XCD -- cut the fabric reads 3x and was slower: profiles/r01_xcd_mapping.md,
+// tools/_exp/r02_experiments.patch.)
 __device__ __forceinline__ int seed_of_block(int b, int wv, int gw, int gh) {
-#if !DSM_XCD_STRIPS
-    // bottom rows first: in driving scenes they are the expensive seeds (near ground, every pixel has depth, long
-    // lists), the top rows are sky and leave after the gather.  Workgroups are dispatched in index order and the
-    // grid does not fit the machine at once, so what is dispatched last must be what finishes fastest.
     const int n_blocks = (gw * gh + 3) >> 2;
     const int s = (n_blocks - 1 - b) * 4 + wv;
     return s < gw * gh ? s : -1;
-#endif
-    const int spr = strip_blocks_per_row(gw);
-    const int strip = b & 7, i = b >> 3;
-    const int gy = i / spr, gx = ((strip * spr + i % spr) << 2) + wv;
-    return (gx < gw && gy < gh) ? gy * gw + gx : -1;
 }
 
 // Launches batched over handles (grid z = handle): which handle and which block of it this workgroup takes.
 // Workgroups go to the XCDs round-robin in dispatch order (x fastest, then z), so with the handle taken from the
 // low bits of the dispatch index a batch of eight puts each handle on ONE XCD: the overlapping windows of a frame
 // then meet in one L2 instead of being fetched over the fabric by all eight.
-#ifndef DSM_BATCH_XCD
-#define DSM_BATCH_XCD 1
-#endif
 struct BlockOf { int z, x, y; };
 template <bool BATCH> __device__ __forceinline__ BlockOf block_of() {
     if (!BATCH) return {0, (int)blockIdx.x, (int)blockIdx.y};
-#if DSM_BATCH_XCD
     const unsigned l = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), r = l / gridDim.z;
     return {(int)(l % gridDim.z), (int)(r % gridDim.x), (int)(r / gridDim.x)};
-#else
-    return {(int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y};
-#endif
 }
 
 // A pointer loaded from memory is a generic pointer to the compiler: loads through it are flat_load (address-space check
@@ -613,103 +567,6 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
     update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
 }
 
-// The same kernel with the window loads staged through LDS (DSM_TILED_UPDATE=1): a workgroup is a 2x2 block of
-// seeds, whose four 16x16 windows cover a 24x24-pixel tile; every tile pixel is fetched (and, for APPLY, resolved to
-// its new label) once per workgroup instead of once per window -- 2.25 instead of 4 fetches per pixel over the fabric --
-// and the waves gather their windows from LDS.
-constexpr int kTile = 3 * kCell; // 24
-template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds_tiled(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    const DeviceCtx *__restrict__ c = BATCH ? batch + blockIdx.z : &ctx; // BATCH: one launch covers several handles (blockIdx.z)
-    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
-    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
-    __shared__ int s_tl[kTile * kTile];   // label of this sweep (-1 outside the image)
-    __shared__ float s_td[kTile * kTile]; // depth
-    __shared__ int s_ti[kTile * kTile];   // intensity
-    const int tid = threadIdx.x, wv = tid >> 6, lane = lane_id();
-    const int gw = c->gw, gh = c->gh;
-    const int nbx = (gw + 1) >> 1, nby = (gh + 1) >> 1;
-    const int bb = nbx * nby - 1 - (int)blockIdx.x; // bottom rows first, see seed_of_block
-    const int bx = bb % nbx, by = bb / nbx;
-    const int gx = 2 * bx + (wv & 1), gy = 2 * by + (wv >> 1);
-    const bool live = gx < gw && gy < gh;
-    const int s = gy * gw + gx;
-    const FrameParams &fp = frame_params(c);
-    const uint8_t *img = frame_image(c, fp);
-    const float *dep = frame_depth(c, fp);
-    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
-    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
-    const int w = c->w, h = c->h, pitch = c->pitch;
-    const int tx0 = 2 * kCell * bx - kCell / 2, ty0 = 2 * kCell * by - kCell / 2;
-    int t_self = kIntMax;
-    float4 old = make_float4(0, 0, 0, 0);
-    if (live) {
-        t_self = c->tmin[s];
-        old = c->core[s];
-    }
-    {
-        int l[3], cd[3], pi[3], pp[3];
-        float d[3];
-        bool in[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) { // independent loads, one round trip
-            const int idx = q * 256 + tid;
-            const int x = tx0 + idx % kTile, y = ty0 + idx / kTile;
-            in[q] = idx < kTile * kTile && x >= 0 && x < w && y >= 0 && y < h;
-            pp[q] = in[q] ? y * pitch + x : 0;
-            l[q] = label_in[pp[q]];
-            if (APPLY) cd[q] = c->cand[pp[q]];
-            d[q] = dep[pp[q]];
-            pi[q] = (int)img[pp[q]];
-        }
-        if (APPLY) {
-            int tl[3];
-#pragma unroll
-            for (int q = 0; q < 3; q++) tl[q] = c->tmin[l[q] >= 0 ? l[q] : 0];
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int idx = q * 256 + tid;
-                const int x = tx0 + idx % kTile, y = ty0 + idx / kTile;
-                if (l[q] >= 0 && tl[q] < pp[q]) l[q] = cd[q];
-                // every pixel of the block's 2x2 cells is stored by this block (ragged right / bottom pixels belong to the last cells)
-                const int ox = (x >> 3) < gw ? (x >> 3) : gw - 1, oy = (y >> 3) < gh ? (y >> 3) : gh - 1;
-                if (in[q] && (ox >> 1) == bx && (oy >> 1) == by) label_out[pp[q]] = l[q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int idx = q * 256 + tid;
-            if (idx < kTile * kTile) {
-                s_tl[idx] = in[q] ? l[q] : -1;
-                s_td[idx] = d[q];
-                s_ti[idx] = pi[q];
-            }
-        }
-    }
-    __syncthreads();
-    if (!live || t_self == kIntMax) return; // stable: FF.cpp:479-480
-    stamp(c, sweep, s, 0, lane);
-    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
-    float *dl = s_depth[wv], *lt = s_term[wv];
-    int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        const int t = (y - ty0) * kTile + (x - tx0);
-        // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
-        const bool mem = s_tl[t] == s && x < w - 1 && y < h - 1;
-        const float d = mem ? s_td[t] : 0.0f;
-        if (mem) {
-            cnt += 1; sdx += idx & (kWin - 1); sdy += idx >> 4; si += s_ti[t];
-        }
-        const bool dv = mem && d > flt_below(0.1); // FF.cpp:508, (double)d > 0.1
-        const unsigned long long m = __ballot(dv);
-        if (dv) dl[nd + rank_below(m)] = d;
-        nd += __popcll(m);
-    }
-    update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
-}
-
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
 template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
@@ -865,10 +722,14 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
         pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
         wave_lds_sync();
         stamp(c, 3, s, 2, lane);
-        if (!((float)m_in / (float)n < flt_above(0.8))) { // FF.cpp:862, (double)ratio < 0.8
+        if (m_in > kGnCap) {
+            // more inliers than a superpixel can have (15 x 15 = 225 members): the label image did not come from
+            // k_assign (dsm_debug_set_label_buffer).  The hand-off to the fit holds kGnCap points: report, no fit.
+            if (lane == 0) atomicOr(c->status, kStatusBadLabels);
+        } else if (!((float)m_in / (float)n < flt_above(0.8))) { // FF.cpp:862, (double)ratio < 0.8
             // sequential fp32 sums, FF.cpp:852-857 and 111-116
             // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
-            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in, true);
+            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in);
             float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2);
             float mx = __shfl(part, 3), my = __shfl(part, 4), mz = __shfl(part, 5);
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
@@ -943,17 +804,6 @@ __device__ __forceinline__ double fit_ordered_sum_core(const float *xc, const fl
     const float4 *x4 = reinterpret_cast<const float4 *>(xc), *y4 = reinterpret_cast<const float4 *>(yc);
     float4 xa = x4[0], xb = x4[1], ya = y4[0], yb = y4[1];
     double acc = 0.0;
-#if DSM_RELAXED_SUMS
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int b = 8; b <= m8; b += 8) {
-        const int nb = b < m8 ? b >> 2 : 0;
-        const float4 pxa = x4[nb * xs], pxb = x4[nb * xs + 1], pya = y4[nb * ys], pyb = y4[nb * ys + 1];
-        acc += (double)(xa.x * ya.x); a1 += (double)(xa.y * ya.y); a2 += (double)(xa.z * ya.z); a3 += (double)(xa.w * ya.w);
-        acc += (double)(xb.x * yb.x); a1 += (double)(xb.y * yb.y); a2 += (double)(xb.z * yb.z); a3 += (double)(xb.w * yb.w);
-        xa = pxa; xb = pxb; ya = pya; yb = pyb;
-    }
-    return 2.0 * ((acc + a1) + (a2 + a3));
-#endif
     for (int b = 8; b <= m8; b += 8) {
         const int nb = b < m8 ? b >> 2 : 0; // (the last round re-reads block 0 and drops it)
         const float4 pxa = x4[nb * xs], pxb = x4[nb * xs + 1], pya = y4[nb * ys], pyb = y4[nb * ys + 1];
@@ -1942,14 +1792,8 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     } while (0)
     const int S = hc.n_seed;
     const dim3 g_seed_thr((S + 255) / 256);
-#if DSM_XCD_STRIPS
-    const dim3 g_seed_wave(8 * ((((hc.gw + 3) / 4 + 7) / 8) * hc.gh)); // 8 strips x blocks per strip (seed_of_block)
-#else
     const dim3 g_seed_wave((S + 3) / 4);
-#endif
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
-    const dim3 g_seed_tile(((hc.gw + 1) / 2) * ((hc.gh + 1) / 2));
-    (void)g_seed_tile;
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
     hipLaunchStage(k_init_seeds<false>, k_init_seeds<true>, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256));
@@ -1958,22 +1802,14 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
         if (sweep == 0) {
             hipLaunchStage((k_assign<true, false>), (k_assign<true, true>), g_tile, dim3(256), sweep);
             DSM_MARK();
-#if DSM_TILED_UPDATE
-            hipLaunchStage((k_update_seeds_tiled<false, false>), (k_update_seeds_tiled<false, true>), g_seed_tile, dim3(256), sweep);
-#else
             hipLaunchStage((k_update_seeds<false, false>), (k_update_seeds<false, true>), g_seed_wave, dim3(256), sweep);
-#endif
             DSM_MARK();
         } else {
             hipLaunchStage((k_assign<false, false>), (k_assign<false, true>), g_tile, dim3(256), sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
             DSM_MARK();
-#if DSM_TILED_UPDATE
-            hipLaunchStage((k_update_seeds_tiled<true, false>), (k_update_seeds_tiled<true, true>), g_seed_tile, dim3(256), sweep);
-#else
             hipLaunchStage((k_update_seeds<true, false>), (k_update_seeds<true, true>), g_seed_wave, dim3(256), sweep);
-#endif
             DSM_MARK();
         }
         hipLaunchStage(k_commit_seeds<false>, k_commit_seeds<true>, g_seed_thr, dim3(256), sweep);

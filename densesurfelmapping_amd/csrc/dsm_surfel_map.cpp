@@ -173,7 +173,7 @@ struct dsm_surfel_map {
     std::vector<PoseElement> poses_database;                                     // :120
     std::set<int> local_surfels_indexs;                                          // :122
     std::vector<Segment> segments;                                               // inactive set, store order (:134)
-    int64_t poses_dropped = 0;
+    int64_t poses_dropped = 0, frames_dropped = 0;
     bool failed = false; // an engine call failed half-way through a state change: refuse further input
     Mat4 transform_kitti = identity4();                                          // function-static at surfel_map.cpp:215
     int64_t frames_fused = 0;
@@ -370,6 +370,7 @@ int synchronize_msgs(dsm_surfel_map *m) {
             else { find_depth = t == pose_reference_time; lost |= !find_depth; break; }
         }
         if (!lost) break;
+        fprintf(stderr, "dsm_surfel_map: the frame of the pose stamped %.6f was never received or already dropped; pose skipped\n", pose_reference_time);
         m->pose_reference_buffer.pop_front();
         m->poses_dropped++;
     }
@@ -415,8 +416,13 @@ int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, std::vector<uint8_t 
     for (int y = 0; y < height; y++) memcpy(f.bytes + (size_t)y * width * elem, (const uint8_t *)data + (size_t)y * step, (size_t)width * elem);
     buffer.push_back(f);
     // frames nobody claims (no pose ever arrives for them) must not pile up in page-locked memory: the oldest go
-    const size_t keep = m->cfg.max_buffered_frames > 0 ? (size_t)m->cfg.max_buffered_frames : 256;
+    // (default 5000 = the reference's subscriber queue depth, ros_node.cpp:24-25; a drop is reported, never silent)
+    const int lim = m->cfg.max_buffered_frames;
+    const size_t keep = lim > 0 ? (size_t)lim : lim == 0 ? (size_t)5000 : (size_t)-1;
     while (buffer.size() > keep) {
+        fprintf(stderr, "dsm_surfel_map: more than %zu %s frames wait for a pose; dropping the one stamped %.6f (its pose will be skipped)\n",
+                keep, elem == 1 ? "image" : "depth", to_sec(buffer.front().stamp));
+        m->frames_dropped++;
         pool.push_back(buffer.front().bytes);
         buffer.pop_front();
     }
@@ -470,6 +476,7 @@ extern "C" {
 int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out) {
     if (!cfg || !out) return DSM_E_INVALID;
     *out = nullptr;
+    if (cfg->struct_size != sizeof(dsm_surfel_map_config)) return DSM_E_INVALID; // built against another header
     if (cfg->drift_free_poses < 1) return DSM_E_INVALID;
     dsm_surfel_map *m = new dsm_surfel_map();
     m->cfg = *cfg;

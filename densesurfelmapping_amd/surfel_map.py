@@ -31,7 +31,7 @@ class _Stamp(C.Structure):
 
 
 class _MapConfig(C.Structure):
-    _fields_ = [("cam_width", C.c_int32), ("cam_height", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("cam_width", C.c_int32), ("cam_height", C.c_int32),
                 ("cam_fx", C.c_float), ("cam_fy", C.c_float), ("cam_cx", C.c_float), ("cam_cy", C.c_float),
                 ("fuse_far_distence", C.c_float), ("fuse_near_distence", C.c_float),
                 ("drift_free_poses", C.c_int32), ("rgbd", C.c_int32), ("device", C.c_int32),
@@ -82,7 +82,7 @@ class SurfelMap:
         # _library: tests bind the same class to their CPU stand-in build of the host logic (tests/node_hostemu.cpp)
         self._lib = _bind(_library if _library is not None else api.load_library())
         self.cam = cam
-        cfg = _MapConfig(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near, drift_free_poses,
+        cfg = _MapConfig(C.sizeof(_MapConfig), cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.far, cam.near, drift_free_poses,
                          1 if cam.rgbd else 0, device, surfel_capacity, max_buffered_frames)
         h = _vp()
         rc = self._lib.dsm_surfel_map_create(C.byref(cfg), C.byref(h))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 1
+#define DSM_ABI_VERSION 2
 
 typedef enum {
     DSM_OK = 0,
@@ -97,6 +97,8 @@ typedef struct dsm_config {
                                      on other slots (live feeds).  Off by default: HIP spreads streams over 4
                                      hardware queues in creation order, and one more stream per handle spreads the
                                      map streams of many handles unevenly (8-subsequence replay: -22 %). */
+
+#define DSM_FLAG_WAVE_STAMPS 4u /* debug: allocate the per-wave phase-stamp buffer read by dsm_debug_wave_stamps */
 
 typedef struct dsm_handle dsm_handle;
 
@@ -238,8 +240,12 @@ int dsm_debug_get_seed_state(dsm_handle *h, float *core4, int32_t *stable);
 int dsm_debug_set_seed_state(dsm_handle *h, const float *core4, const int32_t *stable);
 
 /* debug tap: shader-clock stamps of the phases of the per-seed kernels, [5][n_seed][8] (kernel 0..2 =
- * update_seeds of sweep 0..2, 3 = seed_points, 4 = seed_fit at the first seed of each group of four); needs DSM_WAVE_STAMPS=1 in the environment at dsm_create */
+ * update_seeds of sweep 0..2, 3 = seed_points, 4 = seed_fit at the first seed of each group of four); needs DSM_FLAG_WAVE_STAMPS in dsm_config.flags */
 int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out);
+
+/* test knob: longest point list (<= 120) the short-column tier of the batched plane fit takes; fresh handles only (before the
+ * first frame, before dsm_batch_create) */
+int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap);
 
 /* ---- per-kernel timing (hip events on the handle's stream) ----------------------------- */
 #define DSM_MAX_STAGES 32

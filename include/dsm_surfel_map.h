@@ -45,6 +45,8 @@ typedef struct dsm_pose_msg {
 
 /* the node's parameters (surfel_map.cpp:13-28) */
 typedef struct dsm_surfel_map_config {
+    uint32_t struct_size;    /* sizeof(dsm_surfel_map_config) of the caller's header: a caller built against another
+                                layout is refused (DSM_E_INVALID) instead of having trailing fields read from garbage */
     int32_t cam_width, cam_height;
     float cam_fx, cam_fy, cam_cx, cam_cy;
     float fuse_far_distence, fuse_near_distence; /* spelling of the reference's parameter names */
@@ -52,8 +54,9 @@ typedef struct dsm_surfel_map_config {
     int32_t rgbd;            /* constant set of fusion_functions.h:17-21 instead of :7-16 */
     int32_t device;          /* HIP device ordinal */
     int32_t surfel_capacity; /* active-map capacity, 0 = default of dsm_create */
-    int32_t max_buffered_frames; /* images / depths kept waiting for a pose, oldest dropped beyond; 0 = 256 (the
-                                    reference's buffers are unbounded lists, surfel_map.h:96-97) */
+    int32_t max_buffered_frames; /* images / depths kept waiting for a pose, oldest dropped (and reported on stderr)
+                                    beyond; 0 = 5000, the depth of the reference's subscriber queues (ros_node.cpp:24-25;
+                                    its own lists behind them are unbounded, surfel_map.h:96-97); < 0 = unbounded */
 } dsm_surfel_map_config;
 
 int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out); /* SurfelMap::SurfelMap */

@@ -105,6 +105,7 @@ class SurfelMap {
 
     explicit SurfelMap(const Params &p) {
         dsm_surfel_map_config c = dsm_surfel_map_config();
+        c.struct_size = sizeof c;
         c.cam_width = p.cam_width;
         c.cam_height = p.cam_height;
         c.cam_fx = p.cam_fx;

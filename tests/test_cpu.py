@@ -309,7 +309,7 @@ def test_c_abi_exports_every_declared_symbol():
         for name in declared:
             assert hasattr(lib, name), name
     lib.dsm_abi_version.restype = C.c_int
-    assert lib.dsm_abi_version() == 1
+    assert lib.dsm_abi_version() == 2
     assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
 
 

@@ -258,21 +258,21 @@ def test_batched_replay_matches_stepwise(mods):
 
 
 @pytest.mark.parametrize("fit_small_cap", [None, 40, 0])
-def test_batched_lockstep_replay(mods, monkeypatch, fit_small_cap):
+def test_batched_lockstep_replay(mods, fit_small_cap):
     """dsm_batch_*: five handles with five different scenes advance in lockstep, every kernel launched once for all of
     them (grid z = handle); each subsequence's map equals the oracle's for its own scene, and a handle used alone
     afterwards continues correctly.  Batched launches fit the seed planes in two tiers (short LDS columns for nearly
     all groups of seeds, a queue worked off by a full-length kernel for the rest); these scenes never fill the queue,
     so the runs with a lowered limit send most (40) or all (0) groups through it."""
     api, synth, ob = mods
-    if fit_small_cap is not None:
-        monkeypatch.setenv("DSM_FIT_SMALL_CAP", str(fit_small_cap))
     cam = synth.VGA_DRIVE
     n, B = 14, 5
     scenes = [synth.Scene(seed=200 + 7 * b, n_boxes=6 + b) for b in range(B)]
     handles, plans, frames = [], [], []
     for b in range(B):
         ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 18, pipeline_depth=1)
+        if fit_small_cap is not None:
+            ff.debug_set_fit_small_cap(fit_small_cap)
         fr = list(synth.sequence(cam, scenes[b], n))
         for t, img, dep, pose, ref in fr:
             ff.frame_upload(t, img, dep)

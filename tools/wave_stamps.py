@@ -1,17 +1,16 @@
 #!/usr/bin/env python
-"""Per-wave phase timing of the per-seed kernels (DSM_WAVE_STAMPS=1): where does a wave's life go?"""
+"""Per-wave phase timing of the per-seed kernels (DSM_FLAG_WAVE_STAMPS): where does a wave's life go?"""
 import os
 import sys
 
 import numpy as np
 
-os.environ["DSM_WAVE_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densesurfelmapping_amd import api, synth  # noqa: E402
 
 cam, scene = synth.KITTI_1226, synth.Scene()
 n = 12
-ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 20, flags=api.DSM_FLAG_NO_GRAPH)
+ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=1 << 20, flags=api.DSM_FLAG_NO_GRAPH | api.DSM_FLAG_WAVE_STAMPS)
 frames = list(synth.sequence(cam, scene, n))
 for t, img, dep, pose, ref in frames:
     ff.frame_upload(t, img, dep)
