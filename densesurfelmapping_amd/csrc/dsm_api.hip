@@ -783,11 +783,12 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.fused_flag, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.seed_weight, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_idx, (size_t)c.n_seed));
-        int32_t *ps = nullptr; // work_count, cursor, assign_done, fit_big_count
+        int32_t *ps = nullptr; // work_count, cursor, assign_done, fit_big_count, rest_count[3]
         CREATE_TRY(dev_alloc(h, &ps, 64));
-        q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16; q.fit_big_count = ps + 24;
+        q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16; q.fit_big_count = ps + 24; q.rest_count = ps + 32;
         q.fit_small_cap = kFitSmallCap;
         CREATE_TRY(dev_alloc(h, &q.cur, 1));
+        CREATE_TRY(dev_alloc(h, &q.rest_list, (size_t)((c.n_seed + 63) / 64) * kRestListCap * 64));
         if (cfg->flags & DSM_FLAG_WAVE_STAMPS) CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));
         q.params = h->d_params;
         if (np > 1) CREATE_TRY(hipEventRecord(pp.ev_map, h->stream)); // "buffers free"

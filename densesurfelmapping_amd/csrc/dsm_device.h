@@ -38,6 +38,7 @@ struct GnHeader {
     float far2;        // squared superpixel radius (FF.cpp:820-824)
 };
 constexpr int kGnCap = 232;
+constexpr int kRestListCap = 127; // = kLaneCap of k_update_seeds: the longest list a lane keeps in LDS
 constexpr int kFitSmallCap = 120; // longest list the short-column tier of k_seed_fit takes (batched launches)
 
 // Everything a kernel needs.  Passed to every kernel BY VALUE (kernel-argument segment): the pointers and
@@ -73,6 +74,9 @@ struct DeviceCtx {
     int32_t *work_count;
     int32_t fit_small_cap;  // kFitSmallCap, or less (dsm_debug_set_fit_small_cap: lets a test push ordinary groups through the other tier)
     int32_t *fit_big_count; // groups of seeds queued in `worklist` for the full-length tier of k_seed_fit (batched launches)
+    int32_t *rest_count;    // [kSweeps][2] entries k_update_seeds queued in `worklist` for k_update_seeds_rest (batched launches):
+                            // seeds that need more Huber passes | seeds whose depth list outgrew its LDS row
+    float *rest_list;       // [ceil(S / 64)][kRestListCap][64] depth lists of the queued seeds, entry-major within a group of 64
     GnHeader *gn_hdr; // [S]
     float *gn_pts;    // [S][3][kGnCap]
     dsm_seed *seeds; // [S] final seed table, reference layout

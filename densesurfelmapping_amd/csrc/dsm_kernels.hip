@@ -45,6 +45,13 @@ __device__ __forceinline__ int wave_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_max_int(int v) { // v >= 0 in every lane
+#define DSM_DPP_MAXI(ctrl, rows) v = max(v, __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, false))
+    DSM_DPP_MAXI(0x111, 0xf); DSM_DPP_MAXI(0x112, 0xf); DSM_DPP_MAXI(0x114, 0xf); DSM_DPP_MAXI(0x118, 0xf);
+    DSM_DPP_MAXI(0x142, 0xa); DSM_DPP_MAXI(0x143, 0xc);
+#undef DSM_DPP_MAXI
+    return __builtin_amdgcn_readlane(v, 63);
+}
 // v >= 0 in every lane (identity +0.0f)
 __device__ __forceinline__ float wave_max(float v) {
 #define DSM_DPP_MAX(ctrl, rows) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false)))
@@ -151,6 +158,8 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DSM_G(worklist);
     DSM_G(work_count);
     DSM_G(fit_big_count);
+    DSM_G(rest_count);
+    DSM_G(rest_list);
     DSM_G(gn_hdr);
     DSM_G(gn_pts);
     DSM_G(seeds);
@@ -214,6 +223,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
     const int s = blk.x * kInitSeedsPerBlock + tid / kInitLanes;
     if (blk.x == 0 && tid < kSweeps * kWorkers) c->first_empty[tid] = kIntMax;
     if (blk.x == 0 && tid == 0) c->work_count[0] = c->fit_big_count[0] = 0;
+    if (blk.x == 0 && tid < 2 * kSweeps) c->rest_count[tid] = 0;
     // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
     const FrameParams &fp = c->params[(unsigned)(c->cursor[0] * c->cursor_mul + c->cursor_add) % (unsigned)c->n_params];
     const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
@@ -408,6 +418,41 @@ __device__ __forceinline__ float huber_ordered_sum(const float *lt, int nd, cons
     return a;
 }
 
+// Huber-Newton passes it0 .. 4 of one seed's robust mean depth by one whole wave (FF.cpp:530-556), starting from md.
+// dl[0..nd) = the member depths in order, dl and lt padded with +0.0f to a multiple of kBlk.  The loop-carried part of a
+// pass is only the ordered fp32 sum of the per-element terms; residuals and their classification are lane-parallel.
+__device__ __forceinline__ float huber_passes_wave(const float *dl, float *lt, int nd, float md, int it0, double hr, int lane) {
+    const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
+    float dk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) dk[k] = (k * 64 + lane < nd) ? dl[k * 64 + lane] : 0.0f;
+    const int nk = (nd + 63) >> 6;
+    for (int it = it0; it < 5; it++) {
+        unsigned long long tail[4] = {0, 0, 0, 0}, pos[4] = {0, 0, 0, 0};
+        int n_core = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= nk) break;
+            const int idx = k * 64 + lane;
+            const bool valid = idx < nd;
+            const float r = md - dk[k];
+            const bool core = valid && fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
+            if (valid) lt[idx] = 2 * r;
+            tail[k] = __ballot(valid && !core);
+            pos[k] = __ballot(valid && !core && r > 0);
+            n_core += __popcll(__ballot(core));
+        }
+        wave_lds_sync();
+        const float a = huber_ordered_sum(lt, nd, tail, pos, hr);
+        const float b = (float)(2 * n_core); // the reference adds 2.0f per core element: exact
+        const float delta = huber_newton_step(a, b);
+        md = md + delta;
+        wave_lds_sync();
+        if (fabsf(delta) < flt_above(0.01)) break; // (double)delta < 0.01 && (double)delta > -0.01
+    }
+    return md;
+}
+
 // ------------------------------------------------------------------------------ update seeds
 // One wave per seed.  Lanes cover the 16x16 window (4 pixels each, row-major across k*64+lane).
 // Counts and coordinate/intensity sums are integers (exact in the reference's fp32 accumulators,
@@ -445,42 +490,12 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
     // of nd adds, up to six of them): let it issue ahead of the short ones sharing its SIMD.
     wave_priority(nd);
     if (nd > 0) {
-        // FF.cpp:530-556.  The loop-carried part of a Huber-Newton pass is only the ordered fp32 sum of
-        // the per-element terms; residuals and their classification are computed lane-parallel.
-        const double hr = c->huber;
-        const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
         pad_column(dl, nd, lane);
-        pad_column(lt, nd, lane); // pad slots stay +0.0f: the passes below only write valid slots
+        pad_column(lt, nd, lane); // pad slots stay +0.0f: the passes only write valid slots
         wave_lds_sync();
         md = ordered_sum(dl, nd) / (float)nd;
         stamp(c, sweep, s, 4, lane);
-        float dk[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) dk[k] = (k * 64 + lane < nd) ? dl[k * 64 + lane] : 0.0f;
-        const int nk = (nd + 63) >> 6;
-        for (int it = 0; it < 5; it++) {
-            unsigned long long tail[4] = {0, 0, 0, 0}, pos[4] = {0, 0, 0, 0};
-            int n_core = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k >= nk) break;
-                const int idx = k * 64 + lane;
-                const bool valid = idx < nd;
-                const float r = md - dk[k];
-                const bool core = valid && fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
-                if (valid) lt[idx] = 2 * r;
-                tail[k] = __ballot(valid && !core);
-                pos[k] = __ballot(valid && !core && r > 0);
-                n_core += __popcll(__ballot(core));
-            }
-            wave_lds_sync();
-            const float a = huber_ordered_sum(lt, nd, tail, pos, hr);
-            const float b = (float)(2 * n_core); // the reference adds 2.0f per core element: exact
-            const float delta = huber_newton_step(a, b);
-            md = md + delta;
-            wave_lds_sync();
-            if (fabsf(delta) < flt_above(0.01)) break; // (double)delta < 0.01 && (double)delta > -0.01
-        }
+        md = huber_passes_wave(dl, lt, nd, md, 0, c->huber, lane);
     }
     stamp(c, sweep, s, 5, lane);
     if (c->stamps && lane == 0) c->stamps[((int64_t)sweep * c->n_seed + s) * 8 + 7] = nd;
@@ -490,17 +505,13 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
     }
 }
 
-template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    const BlockOf blk = block_of<BATCH>();
-    DeviceCtx batch_ctx;
-    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
-    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
-    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
-    const int wv = threadIdx.x >> 6, lane = lane_id();
-    // (one seed per wave: the index lives in a scalar register, and so does every address formed from it)
-    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh));
-    if (s < 0) return;
+// update_seeds for ONE seed by one whole wave (lanes cover the 16x16 window, 4 pixels each): the form every seed took
+// until round 3.  Today it serves the seeds whose depth list outgrows the lane-per-seed kernel's LDS rows (below).
+// s is wave-uniform; dl / lt are two lists of 256 floats in LDS owned by this wave.  STORE: also write the sweep's new
+// labels of the seed's own cell.
+template <bool APPLY, bool STORE>
+__device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c, int sweep, int s, float *dl, float *lt) {
+    const int lane = lane_id();
     stamp(c, sweep, s, 0, lane);
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
@@ -513,7 +524,6 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
     const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
     const int t_self = c->tmin[s];
     const float4 old = c->core[s]; // needed only after the sums: issued with the window loads, not behind them
-    float *dl = s_depth[wv], *lt = s_term[wv];
     stamp(c, sweep, s, 1, lane);
     int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
     int lab[4], pi[4], cd[4], pk[4];
@@ -545,7 +555,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
             const int y = y0 + 4 * k;
             if (tl[k] < pk[k]) lab[k] = cd[k];
             const int oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
-            if (pimg[k] && own_x && oy == gy) st_off(label_out, (unsigned)pk[k] << 2, lab[k]);
+            if (STORE && pimg[k] && own_x && oy == gy) st_off(label_out, (unsigned)pk[k] << 2, lab[k]);
         }
     }
     if (t_self == kIntMax) return; // stable: FF.cpp:479-480
@@ -565,6 +575,332 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
         nd += __popcll(m);
     }
     update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
+}
+
+// One Huber-Newton pass (FF.cpp:536-553) of up to 64 seeds at once, one chain per lane: a = ordered sum of 2*r over the
+// Huber core, +-hr (added in double) per tail element; returns the Newton step -a / (b + 10), b = 2 * (core elements).
+// fetch(i) = element i of this lane's list (i is wave-uniform; any value beyond the list's end); lim = the list's
+// length, 0 for a lane that does not take part.  Lanes past the end of their list add r = +0: a + 0 is a, bit for bit (a is
+// never -0).  Branch-free: in a wave of 64 lists some lane nearly always holds a tail element, and a wave-uniform
+// branch per element costs more than the double-typed add it would skip.
+template <typename Fetch> __device__ __forceinline__ float huber_pass_lanes(Fetch fetch, int lim, float md, double hr) {
+    const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
+    const unsigned hr_lo = (unsigned)__double_as_longlong(hr), hr_hi = (unsigned)(__double_as_longlong(hr) >> 32);
+    float a = 0.0f;
+    int n_tail = 0;
+    float d8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) d8[q] = fetch(q);
+    for (int i = 0; __ballot(i < lim) != 0; i += 8) {
+        float n8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) n8[q] = fetch(i + 8 + q); // next block, in flight during this one
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float r = i + q < lim ? md - d8[q] : 0.0f;
+            const bool core = fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
+            const float a_core = a + 2 * r;
+            // (float)((double)a + (r > 0 ? hr : -1 * hr)): the constant's sign bit by select, its low word is shared
+            const double step = __longlong_as_double((long long)(((unsigned long long)(r > 0 ? hr_hi : hr_hi ^ 0x80000000u) << 32) | hr_lo));
+            const float a_tail = (float)((double)a + step);
+            a = core ? a_core : a_tail;
+            n_tail += core ? 0 : 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) d8[q] = n8[q];
+    }
+    const float b = (float)(2 * (lim - n_tail)); // the reference adds 2.0f per core element: exact
+    return huber_newton_step(a, b);
+}
+
+// ---- update_seeds, ONE LANE PER SEED: a wave takes 64 consecutive seeds (launches batched over handles).
+// The wave-per-seed form above spends most of its instructions on work one lane could do: window addressing, the label
+// apply, the ballot / rank compaction and two wave reductions are repeated by every wave for every window, and the
+// ordered sums of a Huber-Newton pass are serial chains of adds executed by all 64 lanes (546 VALU wave-instructions
+// per seed, profiles/r02_pmc_sq_batch8.md) -- and batched launches are bound by VALU issue, not by bytes.  Here every
+// lane walks its own seed's 16x16 window in row-major order (16-byte loads, rows fetched three ahead), keeps the integer
+// sums and the ordered depth sum in registers, compacts its member depths in order into its own LDS row ([element][lane]:
+// conflict-free whatever the lanes' list lengths), and runs the first Huber-Newton pass as 64 independent chains: one
+// v_add serves 64 seeds.  Same operations on the same operands in the same order as the reference, seed by seed.
+//
+// What the first pass does not finish goes to k_update_seeds_rest through two queues: the 13 % of the seeds that need
+// more passes, packed 64 to a wave again, and the seeds whose list does not fit an LDS row of kLaneCap depths (a
+// superpixel averages 53, the longest of 64 neighbours ~95; 0.05 % of all seeds have more than 127), which get a wave
+// of their own.  Same arithmetic on every path, so which one a seed takes changes nothing in its result.
+constexpr int kLaneCap = kRestListCap; // + the spare row: 32 KB per wave, five waves per CU
+
+struct LaneRow { // one window row of one lane: 16 labels, picks, depths, intensities
+    int4 lab[4], cd[4];
+    float4 dp[4];
+    unsigned im[4];
+};
+template <typename T> __device__ __forceinline__ T ld_vec(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ int comp(const int4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+__device__ __forceinline__ float comp(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    __shared__ __attribute__((aligned(16))) float s_list[(kLaneCap + 1) * 64]; // [element][lane] + one spare row
+    const int lane = lane_id();
+    const int S = c->n_seed;
+    // bottom rows first, see seed_of_block
+    const int s = (((S + 63) >> 6) - 1 - blk.x) * 64 + lane;
+    const bool live = s < S;
+    const int sc = live ? s : S - 1;
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
+    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    int gx, gy;
+    seed_cell(c, sc, gx, gy);
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+    const int t_self = c->tmin[sc];
+    const float4 old = c->core[sc];
+    const bool stats = live && t_self != kIntMax; // stable seeds keep their state: FF.cpp:479-480
+    const int s_match = stats ? s : -2;           // no label is -2
+    // the four 16-byte quads of a window row, as pixel offsets within the row; a quad wholly outside the row (x < 0 at
+    // the left border, x >= pitch where the pitch equals the width) is redirected to an in-range one and masked below
+    int qx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = wx0 + 4 * q;
+        qx[q] = x < 0 ? 0 : (x > pitch - 4 ? pitch - 4 : x);
+    }
+    // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
+    bool col_stat[kWin];
+#pragma unroll
+    for (int j = 0; j < kWin; j++) col_stat[j] = (unsigned)(wx0 + j) < (unsigned)(w - 1);
+    const bool last_col_cell = gx == c->gw - 1, last_row_cell = gy == c->gh - 1;
+
+    auto load_row = [&](int r) {
+        LaneRow R;
+        int y = wy0 + r;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        const unsigned row = (unsigned)__mul24(y, pitch);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned o = row + (unsigned)qx[q], o4 = o << 2;
+            R.lab[q] = ld_vec<int4>(label_in, o4);
+            if (APPLY) R.cd[q] = ld_vec<int4>(c->cand, o4);
+            R.dp[q] = ld_vec<float4>(dep, o4);
+            R.im[q] = ld_vec<unsigned>(img, o);
+        }
+        return R;
+    };
+    struct Tmins { int t[kWin]; };
+    auto gather_tmin = [&](const LaneRow &R) {
+        Tmins T;
+#pragma unroll
+        for (int j = 0; j < kWin; j++) T.t[j] = APPLY ? ld_off(c->tmin, (unsigned)comp(R.lab[j >> 2], j & 3) << 2) : 0;
+        return T;
+    };
+
+    int acc_ci = 0;  // member count << 16 | intensity sum  (<= 225 members, 225 * 255 < 2^16)
+    int colcnt[kWin]; // members per window column (their column sum is sum_j j * colcnt[j]: one add-with-carry per pixel)
+#pragma unroll
+    for (int j = 0; j < kWin; j++) colcnt[j] = 0;
+    int acc_y = 0, cnt_prev = 0; // sum of the members' window rows, from the member count of every row
+    // member depths > 0.1 in window row-major order: element i of this lane at s_list[i * 64 + lane]; `tail` = byte address
+    // of the list's end
+    const unsigned lane4 = (unsigned)lane << 2, tail_cap = ((unsigned)kLaneCap << 8) + lane4;
+    unsigned tail = lane4;
+    float sum = 0.0f; // their sequential fp32 sum, FF.cpp:511
+
+    // one window row of every lane's seed: apply + own-cell labels, membership, sums, depth list
+    auto process_row = [&](const LaneRow &A, const Tmins &T, int r) {
+        const int y = wy0 + r;
+        const int key0 = __mul24(y, pitch) + wx0; // pixel key of the row's first window pixel (compared only where the pixel is real)
+        int lab[kWin];
+#pragma unroll
+        for (int j = 0; j < kWin; j++) {
+            lab[j] = comp(A.lab[j >> 2], j & 3);
+            if (APPLY && T.t[j] < key0 + j) lab[j] = comp(A.cd[j >> 2], j & 3); // new(p) = T[old(p)] < p ? pick(p) : old(p)
+        }
+        if (APPLY) {
+            // the sweep's new labels of this seed's own cell (window rows / columns 4..11; ragged right / bottom pixels
+            // belong to the last cell column / row)
+            const bool own_row = (r >= kCell / 2 && r < kCell / 2 + kCell) || (r >= kCell / 2 + kCell && last_row_cell && y < h);
+            if (live && own_row) {
+                const unsigned o4 = (unsigned)(__mul24(y, pitch) + wx0 + kCell / 2) << 2; // byte offset of window column 4 (>= 0)
+                *reinterpret_cast<int4 *>(reinterpret_cast<char *>(label_out) + o4) = make_int4(lab[4], lab[5], lab[6], lab[7]);
+                *reinterpret_cast<int4 *>(reinterpret_cast<char *>(label_out) + (o4 + 16u)) = make_int4(lab[8], lab[9], lab[10], lab[11]);
+                if (last_col_cell) {
+#pragma unroll
+                    for (int j = 12; j < kWin; j++)
+                        if (wx0 + j < w) st_off(label_out, o4 + 4u * (j - kCell / 2), lab[j]);
+                }
+            }
+        }
+        const int s_row = (unsigned)y < (unsigned)(h - 1) ? s_match : -2;
+        // branch-free: every lane is a different seed, so a branch here only adds exec-mask bookkeeping.  The depth is
+        // stored at the list's end unconditionally and the end advances only past a member depth > 0.1 (a later store
+        // overwrites a rejected one; elements from kLaneCap on collapse into the spare row kLaneCap).
+#pragma unroll
+        for (int j = 0; j < kWin; j++) {
+            const bool mem = lab[j] == s_row && col_stat[j];
+            const int pi = (int)((A.im[j >> 2] >> (8 * (j & 3))) & 0xffu);
+            acc_ci += mem ? pi | 0x10000 : 0;
+            colcnt[j] += mem ? 1 : 0;
+            const float d = comp(A.dp[j >> 2], j & 3);
+            const bool dv = mem && d > flt_below(0.1); // FF.cpp:508, (double)d > 0.1
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(s_list) + (tail < tail_cap ? tail : tail_cap)) = d;
+            tail += dv ? 256u : 0u;
+            sum += dv ? d : 0.0f; // (+0.0f: the running sum of positive depths is never -0)
+            if ((j & 3) == 3) {
+                // pin the accumulators per quad: left alone, the optimiser reassociates the integer sums of the unrolled
+                // pixels into one tree and keeps every lane mask alive for it (they spill to VGPR lanes)
+                asm volatile("" : "+v"(acc_ci), "+v"(sum), "+v"(tail), "+v"(colcnt[j - 3]), "+v"(colcnt[j - 2]), "+v"(colcnt[j - 1]), "+v"(colcnt[j]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int cnt_now = acc_ci >> 16;
+        acc_y += r * (cnt_now - cnt_prev);
+        cnt_prev = cnt_now;
+    };
+
+    // Four row buffers in rotation: a row's loads are issued three rows before it is worked on, the tmin gather of its
+    // (old) labels one row before.  The loop is NOT unrolled further: every wave runs this code once per four rows, and a
+    // fully unrolled window (50 KB of straight-line code) is paced by instruction fetch, not by the SIMD --
+    // measured 82 us per launch against 20 us for the wave-per-seed kernel it replaces.
+    LaneRow B0 = load_row(0), B1 = load_row(1), B2 = load_row(2), B3;
+    Tmins T0 = gather_tmin(B0), T1;
+#pragma unroll 1
+    for (int r = 0; r < kWin; r += 4) {
+        B3 = load_row(r + 3);
+        T1 = gather_tmin(B1);
+        __builtin_amdgcn_sched_barrier(0);
+        process_row(B0, T0, r);
+        if (r + 4 < kWin) B0 = load_row(r + 4);
+        T0 = gather_tmin(B2);
+        __builtin_amdgcn_sched_barrier(0);
+        process_row(B1, T1, r + 1);
+        if (r + 4 < kWin) B1 = load_row(r + 5);
+        T1 = gather_tmin(B3);
+        __builtin_amdgcn_sched_barrier(0);
+        process_row(B2, T0, r + 2);
+        if (r + 4 < kWin) { B2 = load_row(r + 6); T0 = gather_tmin(B0); }
+        __builtin_amdgcn_sched_barrier(0);
+        process_row(B3, T1, r + 3);
+    }
+
+    // ---- per-lane finish: means, stability, robust mean depth (FF.cpp:514-556)
+    const int cnt = acc_ci >> 16, si = acc_ci & 0xffff;
+    const int nd = (int)((tail - lane4) >> 8);
+    const bool empty = stats && cnt == 0;
+    if (empty) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(S, s)], s); // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
+    const bool over = stats && nd > kLaneCap;
+    const bool fin = stats && cnt > 0 && !over;
+    int acc_x = 0;
+#pragma unroll
+    for (int j = 1; j < kWin; j++) acc_x += j * colcnt[j];
+    const int sx = acc_x + cnt * wx0, sy = acc_y + cnt * wy0;
+    const float fn = (float)cnt;
+    const float mi = (float)si / fn, mx = (float)sx / fn, my = (float)sy / fn;
+    const float moved = fabsf(old.z - mi) + fabsf(old.x - mx) + fabsf(old.y - my);
+    const int stable = moved < flt_above(0.2) ? 1 : 0; // (double)moved < 0.2, in fp32 (dsm_math.h, flt_above)
+    float md = 0.0f;
+    bool run = fin && nd > 0;
+    if (run) md = sum / (float)nd;
+    const double hr = c->huber;
+    wave_lds_sync();
+    // ---- the FIRST Huber-Newton pass of all 64 seeds, one chain per lane.  87 % of all seeds are done after it
+    // (|delta| < 0.01: FF.cpp:554).
+    if (__ballot(run) != 0) {
+        const float delta = huber_pass_lanes([&](int i) { return s_list[(i < kLaneCap ? i : kLaneCap) * 64 + lane]; }, run ? nd : 0, md, hr);
+        if (run) md = md + delta;
+        if (fabsf(delta) < flt_above(0.01)) run = false; // (double)delta < 0.01 && (double)delta > -0.01
+    }
+    // ---- the rest goes to k_update_seeds_rest.  Seeds that need more passes (13 %; 3 % need all five) are PACKED there,
+    // 64 to a wave: refining them here leaves sixty lanes idle for four more passes (45 us per launch, measured), and
+    // taking them one after the other by the whole wave is worse (150 us: they are the expensive seeds, long lists full
+    // of tail elements).  A queue entry is (seed, length, mean so far); the list moves to rest_list[entry / 64][i][entry % 64].
+    // Seeds whose list outgrew its LDS row (0.05 %) are queued for a wave of their own.
+    const unsigned long long rm = __ballot(run), om = __ballot(over);
+    if (rm | om) {
+        int base_r = 0, base_o = 0;
+        if (lane == 0) {
+            if (rm) base_r = atomicAdd(&c->rest_count[2 * sweep], __popcll(rm));
+            if (om) base_o = atomicAdd(&c->rest_count[2 * sweep + 1], __popcll(om));
+        }
+        base_r = __builtin_amdgcn_readfirstlane(base_r);
+        base_o = __builtin_amdgcn_readfirstlane(base_o);
+        if (over) c->worklist[4 * S + base_o + rank_below(om)] = s; // (worklist: free between k_resolve and the next k_assign)
+        const int q = base_r + rank_below(rm);
+        if (run) reinterpret_cast<int4 *>(c->worklist)[q] = make_int4(s, nd, __float_as_int(md), 0);
+        const unsigned dst0 = (((unsigned)(q >> 6) * kLaneCap) << 8) + ((unsigned)(q & 63) << 2);
+        const int lim = run ? nd : 0;
+        for (int i = 0; __ballot(i < lim) != 0; i += 4) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (i + t < lim) st_off(c->rest_list, dst0 + ((unsigned)(i + t) << 8), s_list[(i + t) * 64 + lane]);
+        }
+    }
+    if (fin) { // (for a queued seed everything but the depth is final)
+        c->core_stage[s] = make_float4(mx, my, mi, md);
+        c->stable_stage[s] = stable;
+    }
+}
+
+// What k_update_seeds left in its queues.  Workgroups (one wave each) below n_dense = ceil(S / 64): passes 2..5 of the
+// queued seeds, 64 to a wave, one chain per lane over the lists in rest_list (coalesced: 64 lanes read 64 consecutive
+// floats per element).  The workgroups after them: seeds whose list did not fit an LDS row, gathered and refined from
+// scratch by one wave each.
+constexpr int kRestOverBlocks = 32;
+template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds_rest(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    __shared__ __attribute__((aligned(16))) float s_depth[kWin * kWin], s_term[kWin * kWin];
+    const int lane = lane_id();
+    const int S = c->n_seed, n_dense = (S + 63) >> 6;
+    if (blk.x >= n_dense) {
+        const int n_over = c->rest_count[2 * sweep + 1];
+        for (int e = blk.x - n_dense; e < n_over; e += kRestOverBlocks) {
+            update_seed_wave<APPLY, false>(c, sweep, __builtin_amdgcn_readfirstlane(c->worklist[4 * S + e]), s_depth, s_term);
+            wave_lds_sync();
+        }
+        return;
+    }
+    const int n = c->rest_count[2 * sweep];
+    if (blk.x * 64 >= n) return;
+    const int q = blk.x * 64 + lane;
+    const bool live = q < n;
+    const int4 ent = reinterpret_cast<const int4 *>(c->worklist)[live ? q : blk.x * 64];
+    const int s = ent.x, nd = ent.y;
+    float md = __int_as_float(ent.z);
+    const double hr = c->huber;
+    const unsigned src0 = (((unsigned)blk.x * kLaneCap) << 8) + ((unsigned)lane << 2);
+    const int n_max = __builtin_amdgcn_readfirstlane(wave_max_int(live ? nd : 0));
+    bool run = live;
+    for (int it = 1; it < 5; it++) {
+        if (__ballot(run) == 0) break;
+        const float delta = huber_pass_lanes([&](int i) { return ld_off(c->rest_list, src0 + ((unsigned)(i < n_max ? i : 0) << 8)); }, run ? nd : 0, md, hr);
+        if (run) md = md + delta;
+        if (fabsf(delta) < flt_above(0.01)) run = false; // (double)delta < 0.01 && (double)delta > -0.01
+    }
+    if (live) c->core_stage[s].w = md;
+}
+
+// One wave per seed for ALL seeds: the launch for a single handle, where what counts is the kernel's latency -- it ends
+// with its slowest wave (~20 us), the lane-per-seed pair above with the slowest of its two stages each (~45 us) -- and
+// not the instructions issued, which is what bounds launches batched over several handles.  Same results, bit for bit.
+template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds_wave(const DeviceCtx ctx, const DeviceCtx *__restrict__, int sweep) {
+    const DeviceCtx *__restrict__ c = &ctx;
+    __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
+    __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
+    const int wv = threadIdx.x >> 6;
+    // (one seed per wave: the index lives in a scalar register, and so does every address formed from it)
+    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blockIdx.x, wv, c->gw, c->gh));
+    if (s < 0) return;
+    update_seed_wave<APPLY, true>(c, sweep, s, s_depth[wv], s_term[wv]);
 }
 
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
@@ -1793,6 +2129,8 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     const int S = hc.n_seed;
     const dim3 g_seed_thr((S + 255) / 256);
     const dim3 g_seed_wave((S + 3) / 4);
+    const dim3 g_seed_lane((S + 63) / 64); // one lane per seed
+    const dim3 g_seed_rest((S + 63) / 64 + kRestOverBlocks); // packed queue entries, then the seeds with oversized lists
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
@@ -1802,14 +2140,24 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
         if (sweep == 0) {
             hipLaunchStage((k_assign<true, false>), (k_assign<true, true>), g_tile, dim3(256), sweep);
             DSM_MARK();
-            hipLaunchStage((k_update_seeds<false, false>), (k_update_seeds<false, true>), g_seed_wave, dim3(256), sweep);
+            if (batched) {
+                hipLaunchStage((k_update_seeds<false, true>), (k_update_seeds<false, true>), g_seed_lane, dim3(64), sweep);
+                hipLaunchStage((k_update_seeds_rest<false, true>), (k_update_seeds_rest<false, true>), g_seed_rest, dim3(64), sweep);
+            } else {
+                hipLaunchStage(k_update_seeds_wave<false>, k_update_seeds_wave<false>, g_seed_wave, dim3(256), sweep);
+            }
             DSM_MARK();
         } else {
             hipLaunchStage((k_assign<false, false>), (k_assign<false, true>), g_tile, dim3(256), sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
             DSM_MARK();
-            hipLaunchStage((k_update_seeds<true, false>), (k_update_seeds<true, true>), g_seed_wave, dim3(256), sweep);
+            if (batched) {
+                hipLaunchStage((k_update_seeds<true, true>), (k_update_seeds<true, true>), g_seed_lane, dim3(64), sweep);
+                hipLaunchStage((k_update_seeds_rest<true, true>), (k_update_seeds_rest<true, true>), g_seed_rest, dim3(64), sweep);
+            } else {
+                hipLaunchStage(k_update_seeds_wave<true>, k_update_seeds_wave<true>, g_seed_wave, dim3(256), sweep);
+            }
             DSM_MARK();
         }
         hipLaunchStage(k_commit_seeds<false>, k_commit_seeds<true>, g_seed_thr, dim3(256), sweep);

@@ -225,7 +225,7 @@ def test_batched_large_maps_headline_regime(mods, gold):
     seen_less, seen_more = False, False
     for b, (ff, w) in enumerate(zip(handles, which)):
         got = ff.map_download()
-        assert len(got) > 262144
+        assert len(starts[w]) > 262144  # the map the frame was fused into: general tail path, grid-stride fuse
         if w < len(rows):
             assert ff.last_new_count() == rows[w]["n_new"] and len(got) == rows[w]["n_local"], (b, w)
             assert map_sha(got, api.SURFEL_DTYPE) == rows[w]["map_sha256"], f"handle {b} (trial {trials[w]}): map differs from the reference TU's"
@@ -248,8 +248,8 @@ def test_batched_large_maps_headline_regime(mods, gold):
         done += chunk
         for b, (ff, w) in enumerate(zip(handles, which)):
             got = ff.map_download()
-            assert len(got) > 262144
             assert fields_equal(got, models[w].astype(api.SURFEL_DTYPE)) == [], f"handle {b} after {done} frames"
+        assert sum(len(m) > 262144 for m in models) >= 3  # (the 90 % stale start shrinks below the fast-path limit)
     for b, (ff, w) in enumerate(zip(handles, which)):
         assert np.array_equal(ff.labels(), oracles[w].labels()), b
     batch.close()
