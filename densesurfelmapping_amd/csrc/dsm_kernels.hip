@@ -282,11 +282,11 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
 }
 
 // ------------------------------------------------------------------------------ assign
-// One thread per pixel, 64x4-pixel tile per block; the <=10x3 seeds a tile can pick from are staged
-// in LDS.  FIRST sweep: every pixel is evaluated (all labels 0, seed 0 unstable) so the pick is the
-// label.  Later sweeps: the pick goes to `cand`, and the sequential skip rule is resolved through
-// tmin (see k_resolve).
-constexpr int kTileW = 64, kTileH = 4, kTileCellsX = kTileW / kCell + 2, kTileCellsY = 3;
+// One thread per column of FOUR pixels (a 4 x 4 quadrant of a cell shares its <= 2 x 2 candidate seeds: they are fetched
+// once per thread), a 64x16-pixel tile per block; the <=10x4 seeds a tile can pick from are staged in LDS.  FIRST sweep:
+// every pixel is evaluated (all labels 0, seed 0 unstable) so the pick is the label.  Later sweeps: the pick goes to
+// `cand`, and the sequential skip rule is resolved through tmin (see k_resolve).
+constexpr int kTileW = 64, kColumn = 4, kTileH = 4 * kColumn, kTileCellsX = kTileW / kCell + 2, kTileCellsY = kTileH / kCell + 2;
 
 // The reference scans pixels in row-major order; a pixel is skipped iff its current seed is still
 // `stable` when the scan reaches it, and every evaluated pixel clears `stable` of the seed it
@@ -320,6 +320,7 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
+    __shared__ float s_invf[kTileCellsX * kTileCellsY]; // the same rounded to float, for the filtered pick
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
@@ -332,30 +333,56 @@ template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assig
         const int gx = cx0 + tid % kTileCellsX, gy = cy0 + tid / kTileCellsX;
         if (gx >= 0 && gx < gw && gy >= 0 && gy < gh) {
             s_core[tid] = c->core[gy * gw + gx];
-            s_inv[tid] = c->inv_depth[gy * gw + gx];
+            const double inv = c->inv_depth[gy * gw + gx];
+            s_inv[tid] = inv;
+            s_invf[tid] = (float)inv;
         }
     }
     __syncthreads();
-    const int x = bx + (tid & (kTileW - 1)), y = by + tid / kTileW;
-    if (x < w && y < h && !has_candidate_cell(x, y, gw, gh)) {
-        // ragged border beyond every cell's reach: label -1 in both label buffers, once per frame (no later stage
-        // reads or writes these pixels: every seed window ends before them)
-        if (FIRST) c->label[y * pitch + x] = c->label_alt[y * pitch + x] = -1;
-    } else if (x < w && y < h) {
-        const int p = __mul24(y, pitch) + x;
-        const unsigned p4 = (unsigned)p << 2; // byte offset into the 4-byte planes, see ld_off
-        const float pix_i = (float)ld_off(img, (unsigned)p);
-        const float pix_d = ld_off(dep, p4);
-        int l = 0;
-        if (!FIRST) l = ld_off(label_in, p4);
-        const int pick = pick_seed(x, y, pix_i, pix_d, gw, gh,
-                                   [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
-                                       const int li = (gy - cy0) * kTileCellsX + (gx - cx0);
-                                       const float4 v = s_core[li];
-                                       sx = v.x; sy = v.y; si = v.z;
-                                       has_d = v.w > 0;
-                                       inv_d = s_inv[li];
-                                   });
+    const int x = bx + (tid & (kTileW - 1)), y0 = by + (tid / kTileW) * kColumn; // y0 is a multiple of 4: one quadrant row
+    if (x >= w || y0 >= h) return;
+    // the column's pixels, one round trip
+    float pix_i[kColumn], pix_d[kColumn];
+    int lab[kColumn];
+    const unsigned p0 = (unsigned)(__mul24(y0, pitch) + x);
+#pragma unroll
+    for (int r = 0; r < kColumn; r++) {
+        const unsigned p = y0 + r < h ? p0 + (unsigned)(r * pitch) : p0, p4 = p << 2; // byte offsets into the 4-byte planes, see ld_off
+        pix_i[r] = (float)ld_off(img, p);
+        pix_d[r] = ld_off(dep, p4);
+        lab[r] = FIRST ? 0 : ld_off(label_in, p4);
+    }
+    const PickQuad quad = pick_quad(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &inv_f) {
+        const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
+        const float4 v = s_core[li];
+        sx = v.x; sy = v.y; si = v.z; sd = v.w;
+        inv_f = s_invf[li];
+    });
+#pragma unroll
+    for (int r = 0; r < kColumn; r++) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        const int p = (int)p0 + r * pitch;
+        const unsigned p4 = (unsigned)p << 2;
+        if (!has_candidate_cell(x, y, gw, gh)) {
+            // ragged border beyond every cell's reach: label -1 in both label buffers, once per frame (no later stage
+            // reads or writes these pixels: every seed window ends before them)
+            if (FIRST) c->label[p] = c->label_alt[p] = -1;
+            continue;
+        }
+        // the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast); the few
+        // near-ties of a wave take the reference's typed arithmetic
+        int pick = pick_seed_fast(quad, x, y, pix_i[r], pix_d[r], gw);
+        if (pick == kPickUnsure)
+            pick = pick_seed(x, y, pix_i[r], pix_d[r], gw, gh,
+                             [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
+                                 const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
+                                 const float4 v = s_core[li];
+                                 sx = v.x; sy = v.y; si = v.z;
+                                 has_d = v.w > 0;
+                                 inv_d = s_inv[li];
+                             });
+        const int l = lab[r];
         if (pick < 0) { // every candidate cost >= the reference's 1e6 sentinel: it would index seeds[-1]
             atomicOr(c->status, kStatusBadPick);
             if (FIRST) st_off(c->label, p4, 0); else st_off(c->cand, p4, l);

@@ -133,6 +133,108 @@ DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, Loa
     return all_depth ? arg_d : arg_n; // FF.cpp:442-451
 }
 
+// The same pick, filtered: what pick_seed must return is an argmin, not the costs, and the costs above are expensive
+// because of their typing (per candidate seven float <-> double conversions and seven double operations, all slower than
+// fp32 on this hardware).  pick_seed_fast evaluates every candidate's cost in plain fp32 (fused multiply-adds allowed)
+// together with a bound on how far that value can be from the reference's, and answers only when the smallest interval
+// lies strictly below all the others and below the 1e6 sentinel: then the reference's strict '<' scan picks the same
+// candidate whatever the order.  Otherwise it returns kPickUnsure and the caller runs pick_seed.
+//
+// Error bound (u = 2^-24; the double roundings of the reference are 2^-29 of that and ignored in the slack).  All three
+// cost terms are >= 0, so sums do not cancel.  Spatial term: the same fp32 operations in both forms except the last
+// add (dist / 16 is an exact scaling): <= 2u relative.  Intensity term: the reference rounds di^2 / 100 to double, adds in
+// double and rounds once to float; here di^2 * RN(0.01) and the add: <= 4u of the sum.  Depth term, D = 1 / mean_depth:
+// the reference forms dd = RN32(D - p) from the double D, here from Df = RN32(D): |dd~ - dd| <= e = u (|Df| + 3 |dd~|);
+// squaring and scaling by 400: |T~ - T| <= 400 e (2 |dd~| + e) + 4u T~; the final add 2u.  In all
+//     |cost~ - cost| <= 10u cost~ + 400 e (2 |dd~| + e),
+// used below with 16u and 800, which also covers the roundings of the bound's own evaluation.
+// tests/hostemu.cpp checks the bound against the reference costs on every candidate of its test frames.
+constexpr int kPickUnsure = -2;
+struct FastCost {
+    float c, err;
+};
+DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float seed_inv_f, bool with_depth, float pix_i, float pix_invd, int x, int y) {
+    const float u = 5.9604645e-8f; // 2^-24
+    const float ddx = sx - (float)x, ddy = sy - (float)y;
+    const float dist = __builtin_fmaf(ddy, ddy, ddx * ddx);
+    const float di = si - pix_i;
+    const float c_no = __builtin_fmaf(dist, 0.0625f, (di * di) * 0.01f);
+    // (no branches: every lane of a wave is another pixel, and the selects cost less than the exec-mask bookkeeping)
+    const float dd = seed_inv_f - pix_invd, ad = fabsf(dd);
+    const float c_with = __builtin_fmaf(dd * dd, 400.0f, c_no);
+    // 800 e (2 |dd| + e) with e = u (|Df| + 3 |dd|), rounded up to e800 (2 |dd| + e800), e800 = 800 e: one operation less
+    const float e800 = __builtin_fmaf(2400.0f * u, ad, (800.0f * u) * fabsf(seed_inv_f));
+    const float slack = e800 * __builtin_fmaf(2.0f, ad, e800);
+    FastCost r;
+    r.c = with_depth ? c_with : c_no;
+    r.err = __builtin_fmaf(20.0f * u, r.c, with_depth ? slack : 0.0f); // (20u: 4u of it for the candidate tag below)
+    return r;
+}
+// The candidates of a pixel are those of its 4 x 4 quadrant of a cell (see pick_seed): PickQuad holds them for all pixels
+// (x, y') with y' / 4 == y / 4, so that a thread working down a column of four pixels fetches them once.
+// load(gx, gy, sx, sy, si, seed_depth, inv_depth_f) fetches the cost-side state of grid cell (gx,gy) -- called for cells
+// clamped into the grid, so it needs no bounds of its own -- with the inverse mean depth rounded to float.
+struct PickQuad {
+    float sx[4], sy[4], si[4], sd[4], sinv[4]; // candidate k = (x offset k >> 1, y offset k & 1), the reference's scan order
+    bool col_ok[2], row_in[2];                  // in the grid and, for columns, past the distance filter
+    int gx0, gy0;
+};
+template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, int gh, LoadSeedF load) {
+    PickQuad q;
+    const int bx = x / kCell, by = y / kCell;
+    const int xr = x % kCell, yr = y % kCell;
+    q.gx0 = bx - (xr < kCell / 2 ? 1 : 0);
+    q.gy0 = by - (yr < kCell / 2 ? 1 : 0);
+    q.col_ok[0] = q.gx0 >= 0 && q.gx0 < gw;
+    q.col_ok[1] = q.gx0 + 1 >= 0 && q.gx0 + 1 < gw && xr != kCell / 2;
+    q.row_in[0] = q.gy0 >= 0 && q.gy0 < gh;
+    q.row_in[1] = q.gy0 + 1 >= 0 && q.gy0 + 1 < gh;
+    for (int k = 0; k < 4; k++) {
+        int gx = q.gx0 + (k >> 1), gy = q.gy0 + (k & 1);
+        gx = gx < 0 ? 0 : (gx > gw - 1 ? gw - 1 : gx);
+        gy = gy < 0 ? 0 : (gy > gh - 1 ? gh - 1 : gy);
+        load(gx, gy, q.sx[k], q.sy[k], q.si[k], q.sd[k], q.sinv[k]);
+    }
+    return q;
+}
+DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pix_d, int gw) {
+    const float invd = pixel_inv_depth(pix_d);
+    const bool row_ok[2] = {q.row_in[0], q.row_in[1] && y % kCell != kCell / 2};
+    bool live[4];
+    bool all_depth = invd > 0;
+    for (int k = 0; k < 4; k++) {
+        live[k] = q.col_ok[k >> 1] && row_ok[k & 1];
+        all_depth = all_depth && (!live[k] || q.sd[k] > 0);
+    }
+    // FF.cpp:442-451: with every candidate's depth term applied the pick is the argmin with it, else the argmin without.
+    // Costs are >= 0, so their bit patterns order like the values; the candidate's position in the reference's scan goes
+    // into the two lowest bits (a change of < 4 ulp, inside the error bound): the smallest tagged cost names the winner.
+    // It is the reference's pick for sure if even the largest error bound of the four separates it from the runner-up
+    // and from the sentinel the scan starts from.
+    uint32_t key[4];
+    float err_max = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        const FastCost f = pixel_cost_fast(q.sx[k], q.sy[k], q.si[k], q.sinv[k], all_depth, pix_i, invd, x, y);
+        err_max = fmaxf(err_max, f.err); // (of a masked candidate too: its cell was clamped to a real one, the bound is merely larger)
+        const uint32_t bits = __builtin_bit_cast(uint32_t, f.c);
+        // a cell outside the grid or past the distance filter never wins; neither does a NaN or negative (sign-bit) cost
+        key[k] = (live[k] && f.c >= 0.0f) ? ((bits & ~3u) | (uint32_t)k) : 0x7f7ffffcu + (uint32_t)k;
+    }
+    const uint32_t lo01 = key[0] < key[1] ? key[0] : key[1], hi01 = key[0] < key[1] ? key[1] : key[0];
+    const uint32_t lo23 = key[2] < key[3] ? key[2] : key[3], hi23 = key[2] < key[3] ? key[3] : key[2];
+    const uint32_t first = lo01 < lo23 ? lo01 : lo23;
+    const uint32_t mid_a = lo01 < lo23 ? lo23 : lo01, mid_b = hi01 < hi23 ? hi01 : hi23;
+    const uint32_t second = mid_a < mid_b ? mid_a : mid_b;
+    const float c1 = __builtin_bit_cast(float, first), c2 = __builtin_bit_cast(float, second);
+    const int k = (int)(first & 3u);
+    if (c1 + err_max < c2 - err_max && c1 + err_max < 1e6f) return (q.gy0 + (k & 1)) * gw + (q.gx0 + (k >> 1));
+    return kPickUnsure;
+}
+template <typename LoadSeedF>
+DSM_HD int pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeedF load) {
+    return pick_seed_fast(pick_quad(x, y, gw, gh, load), x, y, pix_i, pix_d, gw);
+}
+
 // ------------------------------------------------- robust mean depth of a seed, FF.cpp:530-556
 // list[0..n) = member depths > 0.1 in window row-major order, sum = their sequential fp32 sum.
 // Newton step of the robust mean, FF.cpp:553: delta = (float)((double)(-a) / ((double)b + 10.0)), where b = 2 x (core

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <set>
 
 #include "../densesurfelmapping_amd/csrc/dsm_math.h"
 #include "../include/dsm.h"
@@ -33,6 +34,8 @@ struct Emu {
     const uint8_t *img; size_t img_step;
     const float *dep; size_t dep_step;
     int order_salt = 0; // permutes "thread" execution order to exercise order independence
+    std::set<long long> unsure_waves; long long sweep_id = 0;
+    long long fast_total = 0, fast_unsure = 0, fast_mismatches = 0, fast_checked = 0, fast_bound_violations = 0; // pick_seed_fast
 
     float I(int x, int y) const { return (float)img[(size_t)y * img_step + x]; }
     float D(int x, int y) const { return *(const float *)((const char *)dep + (size_t)y * dep_step + (size_t)x * 4); }
@@ -64,6 +67,7 @@ void init_seeds(Emu &e) {
 }
 
 void assign(Emu &e, bool first) {
+    e.sweep_id++;
     e.worklist.clear();
     const int n = e.w * e.h;
     for (int q = 0; q < n; q++) {
@@ -74,12 +78,35 @@ void assign(Emu &e, bool first) {
             if (first) e.label[p] = -1;
             continue;
         }
-        const int pick = pick_seed(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
-                                   [&](int gx, int gy, float &sx, float &sy, float &si, bool &hd, double &inv) {
-                                       const int s = gy * e.gw + gx;
-                                       sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i;
-                                       hd = e.core[s].d > 0; inv = e.inv_depth[s];
-                                   });
+        const int exact = pick_seed(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
+                                    [&](int gx, int gy, float &sx, float &sy, float &si, bool &hd, double &inv) {
+                                        const int s = gy * e.gw + gx;
+                                        sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i;
+                                        hd = e.core[s].d > 0; inv = e.inv_depth[s];
+                                    });
+        // the kernel's filtered pick (dsm_math.h, pick_seed_fast): wherever it answers, it must be the reference's pick
+        const int fast = pick_seed_fast(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
+                                        [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &invf) {
+                                            const int s = gy * e.gw + gx;
+                                            sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i;
+                                            sd = e.core[s].d; invf = (float)e.inv_depth[s];
+                                            const bool hd = sd > 0;
+                                            // ... and its error bound must hold against the reference's typed costs
+                                            const float invd = pixel_inv_depth(e.D(x, y));
+                                            float cn, cd;
+                                            const bool with = pixel_cost(sx, sy, si, hd, e.inv_depth[s], e.I(x, y), invd, x, y, cn, cd);
+                                            for (int depth_term = 0; depth_term < 2; depth_term++) {
+                                                if (depth_term && !with) continue;
+                                                const FastCost f = pixel_cost_fast(sx, sy, si, invf, depth_term != 0, e.I(x, y), invd, x, y);
+                                                const double ref = depth_term ? (double)cd : (double)cn;
+                                                e.fast_checked++;
+                                                if (!(fabs((double)f.c - ref) <= (double)f.err)) e.fast_bound_violations++;
+                                            }
+                                        });
+        e.fast_total++;
+        if (fast == kPickUnsure) { e.fast_unsure++; e.unsure_waves.insert(((long long)e.sweep_id << 40) | (long long)(y * ((e.w + 63) / 64) + x / 64)); }
+        else if (fast != exact) e.fast_mismatches++;
+        const int pick = fast == kPickUnsure ? exact : fast;
         if (first) { e.label[p] = pick; continue; }
         e.cand[p] = pick;
         const int l = e.label[p];
@@ -316,6 +343,12 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 }
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
+// pick_seed_fast over every pixel assigned so far: [pixels, unsure, answered differently from pick_seed, costs checked, bound violated]
+void emu_fast_pick_stats(void *p, long long *out) {
+    Emu &e = *(Emu *)p;
+    out[5] = (long long)e.unsure_waves.size(); out[6] = e.sweep_id;
+    out[0] = e.fast_total; out[1] = e.fast_unsure; out[2] = e.fast_mismatches; out[3] = e.fast_checked; out[4] = e.fast_bound_violations;
+}
 
 int emu_fuse_map(void *p, int ref_idx, const uint8_t *img, size_t img_step, const float *depth, size_t depth_step,
                  const float *pose16, dsm_surfel *local, int *n_local, int cap, int *n_new) {
