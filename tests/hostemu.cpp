@@ -343,7 +343,8 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 }
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
-// pick_seed_fast over every pixel assigned so far: [pixels, unsure, answered differently from pick_seed, costs checked, bound violated]
+// pick_seed_fast over every pixel assigned so far: out[8] = [pixels, unsure, answered differently from pick_seed, costs checked,
+// bound violated, 64-pixel row segments (waves) with an unsure pixel, sweeps]
 void emu_fast_pick_stats(void *p, long long *out) {
     Emu &e = *(Emu *)p;
     out[5] = (long long)e.unsure_waves.size(); out[6] = e.sweep_id;
