@@ -29,6 +29,8 @@ thread_local std::string g_create_error;
 constexpr int kParamRing = 4096;
 constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 
+void batch_streams_reserve(int device); // see BatchStreamPool
+
 } // namespace
 
 // A few host threads for the drop-in calls' bulk copies (frame rows into page-locked staging, the caller's surfel
@@ -703,6 +705,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         }                                                                                 \
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
+    batch_streams_reserve(h->device); // (before any handle stream of this process: see BatchStreamPool)
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->up_stream = h->stream;
     if (cfg->flags & DSM_FLAG_UPLOAD_STREAM) {
@@ -731,6 +734,17 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &img, (size_t)c.slot_elems * c.n_slots));
     CREATE_TRY(dev_alloc(h, &dep, (size_t)c.slot_elems * c.n_slots));
     c.img_base = img; c.depth_base = dep;
+    {   // ray coefficients of every pixel column and row (host and device divide alike: correctly rounded fp32)
+        std::vector<float> rays((size_t)w + 1 + (size_t)hh + 1);
+        for (int x = 0; x <= w; x++) rays[(size_t)x] = ray_coeff(x, cfg->cx, cfg->fx);
+        for (int y = 0; y <= hh; y++) rays[(size_t)w + 1 + (size_t)y] = ray_coeff(y, cfg->cy, cfg->fy);
+        float *d_rays = nullptr;
+        CREATE_TRY(dev_alloc(h, &d_rays, rays.size()));
+        CREATE_TRY(hipMemcpyAsync(d_rays, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream)); // `rays` is on the stack frame's heap block
+        c.ray_x = d_rays;
+        c.ray_y = d_rays + w + 1;
+    }
     CREATE_TRY(dev_alloc(h, &c.local, (size_t)c.cap));
     CREATE_TRY(dev_alloc(h, &c.fresh, (size_t)c.n_seed));
     CREATE_TRY(dev_alloc(h, &c.hole_mask, (size_t)c.cap / 64 + 1));
@@ -776,7 +790,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.tmin, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.first_empty, (size_t)kSweeps * kWorkers));
         CREATE_TRY(dev_alloc(h, &q.gn_hdr, (size_t)c.n_seed));
-        CREATE_TRY(dev_alloc(h, &q.gn_pts, (size_t)c.n_seed * 3 * kGnCap));
+        CREATE_TRY(dev_alloc(h, &q.normals, (size_t)c.slot_elems * 3));
         CREATE_TRY(dev_alloc(h, &q.seeds, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_rec, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_ok, (size_t)c.n_seed));
@@ -1387,10 +1401,43 @@ int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
 } // extern "C"
 
 // ------------------------------------------------------------------ batches
+// Streams for batches, one per hardware queue.  HIP multiplexes its streams over four hardware queues (GPU_MAX_HW_QUEUES)
+// and gives a new stream the queue with the fewest streams on it at that moment: a batch stream created after a few
+// hundred handle streams lands wherever the count happens to be lowest, and two batches that share a queue run one
+// after the other (measured: streams 129..132 of a 128-handle bench on queues 4, 2, 1, 4 -- the two batches on queue 4
+// busy 45 % and 54 % of the time, the other two 78 % and 73 %).  The first four streams of a process, created together
+// before anything else, get a queue each; batches take them in turn.  Created by the first dsm_create on the device.
+namespace {
+constexpr int kBatchStreams = 4;
+struct BatchStreamPool {
+    std::mutex mu;
+    hipStream_t st[64][kBatchStreams] = {};
+    bool made[64] = {};
+    int next[64] = {};
+} g_batch_streams;
+
+void batch_streams_reserve(int device) {
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_batch_streams.mu);
+    if (g_batch_streams.made[device]) return;
+    g_batch_streams.made[device] = true;
+    for (int i = 0; i < kBatchStreams; i++)
+        if (hipStreamCreateWithFlags(&g_batch_streams.st[device][i], hipStreamNonBlocking) != hipSuccess) g_batch_streams.st[device][i] = nullptr;
+}
+hipStream_t batch_stream_take(int device) {
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_batch_streams.mu);
+    if (!g_batch_streams.made[device]) return nullptr;
+    const int i = g_batch_streams.next[device]++ % kBatchStreams;
+    return g_batch_streams.st[device][i];
+}
+} // namespace
+
 struct dsm_batch {
     std::vector<dsm_handle *> hs;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = false; // false: one of the device's reserved batch streams
     DeviceCtx *d_ctxs = nullptr;
     hipGraphExec_t graph = nullptr;
     hipEvent_t ev_out = nullptr;
@@ -1494,7 +1541,11 @@ int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
         }                                                                       \
     } while (0)
     BCREATE_TRY(hipSetDevice(b->device));
-    BCREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->stream = batch_stream_take(b->device);
+    if (!b->stream) {
+        BCREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->own_stream = true;
+    }
     BCREATE_TRY(hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming));
     for (int i = 0; i <= kNumStages + 1; i++) BCREATE_TRY(hipEventCreate(&b->ev[i]));
     b->have_events = true;
@@ -1519,7 +1570,7 @@ void dsm_batch_destroy(dsm_batch *b) {
     if (b->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(b->ev[i]);
     if (b->d_ctxs) (void)hipFree(b->d_ctxs);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
 

@@ -28,9 +28,9 @@ struct FrameCur {
     const float *dep;
 };
 
-// Hand-off from k_seed_points to k_seed_fit: the start of get_huber_norm (FF.cpp:104-126) for one seed.  The centred
-// inlier points follow in gn_pts as three columns of kGnCap floats.  A superpixel's pixels lie within 8 of its centre
-// in both axes (FF.cpp:413-422): at most 15 x 15 = 225 members.
+// Hand-off from k_seed_stats to k_seed_fit: the start of get_huber_norm (FF.cpp:104-120) for one seed; the fit gathers the
+// centred inlier points itself.  A superpixel's pixels lie within 8 of its centre in both axes (FF.cpp:413-422): at most
+// 15 x 15 = 225 members.
 struct GnHeader {
     int32_t m_in;      // inliers handed to the fit; 0 = no fit, the seed keeps its defaults (FF.cpp:841, 862)
     float nx, ny, nz;  // normalised sum of the inliers' pixel normals (FF.cpp:852-871)
@@ -52,6 +52,7 @@ struct DeviceCtx {
     Intrinsics k;
     float far_d, near_d;
     double huber, baseline, disp_err, min_tol;
+    const float *ray_x, *ray_y; // [w + 1], [h + 1]: (x - cx) / fx, (y - cy) / fy of back_project (dsm_math.h, ray_coeff)
     // frame slots (HBM-resident inputs)
     const uint8_t *img_base;
     const float *depth_base;
@@ -78,7 +79,7 @@ struct DeviceCtx {
                             // seeds that need more Huber passes | seeds whose depth list outgrew its LDS row
     float *rest_list;       // [ceil(S / 64)][kRestListCap][64] depth lists of the queued seeds, entry-major within a group of 64
     GnHeader *gn_hdr; // [S]
-    float *gn_pts;    // [S][3][kGnCap]
+    float *normals;   // [h][pitch][3] forward-difference normal of every depth inlier of its own superpixel, zero elsewhere (k_pixel_normals)
     dsm_seed *seeds; // [S] final seed table, reference layout
     // what initialize_surfels (FF.cpp:315-361) would create from each seed, prepared by k_seed_planes (every
     // input but the `fused` flag is known there): the surfel, whether the seed qualifies, the flag itself

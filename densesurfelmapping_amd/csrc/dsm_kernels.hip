@@ -7,8 +7,9 @@
 //   k_resolve       the sequential `stable` skip rule of FF.cpp:400,445,450 as a fixed point
 //   k_update_seeds  update_seeds_kernel              FF.cpp:468-562 (+ the new label image of the sweep)
 //   k_commit_seeds  the early `return` of FF.cpp:516-517 (per worker chunk)
-//   k_seed_points   calculate_spaces/pixels_norms/sp_depth_norms up to the centred inlier points
-//                                                    FF.cpp:644-712, 792-871, 104-126
+//   k_pixel_normals calculate_pixels_norms_kernel (the normals that are read)   FF.cpp:664-712
+//   k_seed_stats    calculate_spaces / calculate_sp_depth_norms up to the fit's starting point
+//                                                    FF.cpp:644-662, 792-871, 104-120
 //   k_seed_fit      get_huber_norm's Gauss-Newton steps, the seed's plane / position / view angle
 //                                                    FF.cpp:128-188, 872-914
 //                   and the per-seed part of initialize_surfels, FF.cpp:315-361
@@ -143,6 +144,8 @@ template <typename T> __device__ __forceinline__ T *as_global(T *p) {
 __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DeviceCtx o = *as_global(src);
 #define DSM_G(f) o.f = as_global(o.f)
+    DSM_G(ray_x);
+    DSM_G(ray_y);
     DSM_G(img_base);
     DSM_G(depth_base);
     DSM_G(label);
@@ -161,7 +164,7 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DSM_G(rest_count);
     DSM_G(rest_list);
     DSM_G(gn_hdr);
-    DSM_G(gn_pts);
+    DSM_G(normals);
     DSM_G(seeds);
     DSM_G(spawn_rec);
     DSM_G(spawn_ok);
@@ -952,14 +955,12 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(cons
 
 // ------------------------------------------------------------------------------ seed planes
 // calculate_spaces / calculate_pixels_norms / calculate_sp_depth_norms + get_huber_norm (FF.cpp:644-712, 792-914,
-// 104-188) in two kernels.
-//
-// k_seed_points, one wave per seed: gather the member pixels with valid depth (window row-major order), keep the
-// depth inliers, recompute their back-projections and forward-difference normals from the depth plane (the
-// reference's 36 B/pixel space_map and norm_map never exist in memory), sum normals and points in the reference's
-// order and hand the centred inlier points to the fit.  Every order-sensitive sum runs in the reference's order,
-// but only the adds are serial: operands are produced lane-parallel, parked in LDS as structure-of-arrays columns
-// and block-fetched; the six fp32 sums are six lanes.
+// 104-188) in three kernels: k_pixel_normals (thread per pixel), k_seed_stats (lane per seed) and k_seed_fit.  The
+// reference's 36 B/pixel space_map never exists in memory (a back-projection is two multiplies by tabulated ray
+// coefficients), its norm_map only for the pixels that are read.  Every order-sensitive sum runs in the reference's
+// order.  (Until round 3 a wave-per-seed kernel, k_seed_points, did the work of the first two and handed the centred
+// inlier points to the fit through a [S][3][232] buffer: 611 VALU instructions per seed, 97 MB of hand-off traffic
+// per batched launch.)
 //
 // k_seed_fit, FOUR seeds per wave: the 5 Huber-weighted Gauss-Newton steps.  A step's 10 + 4 double accumulators
 // (the Hessian is symmetric: H(a,b) and H(b,a) add the same products) are independent ordered sums,
@@ -968,161 +969,215 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(cons
 // i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}: 14 lanes of a 16-lane group
 // each carry one, so four seeds fill the wave where one seed used 20 of 64 lanes (the Gauss-Newton steps were 60 %
 // of the one-kernel form's time).  The 4x4 solve is one lane per 2x2 determinant / adjugate entry, again per group.
-constexpr int kCols = 6; // LDS columns per wave of k_seed_points, reused across phases:
-//   gather / inlier phase:  depth list | packed xy | -       | n0       | n1   | n2
-//   sums phase:             p0         | p1        | p2      | n0       | n1   | n2
-// (p0/p1 overwrite the depth/xy lists in place: a chunk's 64 entries are read before its compacted
-// entries, which land at or below the same indices, are written)
-// column stride: 260 floats shifts successive columns by 4 banks, so that lanes streaming different
-// columns at the same element offset (ds_read_b128) do not collide
-constexpr int kColStride = kWin * kWin + 4;
-
-template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+// ---- seed statistics without a wave per seed
+// k_pixel_normals, one thread per pixel: the forward-difference normal (FF.cpp:664-712) of every pixel that is a depth
+// inlier of its own superpixel (FF.cpp:846-850: member, depth > 0.05, |mean depth - depth| < HUBER_RANGE) and zero for
+// every other pixel -- a 12 B/pixel plane that lives in L2 between two kernels.  (calculate_pixels_norms computes all of
+// them; only these are ever read, FF.cpp:852-857.)
+template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
-    const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh)); // scalar, see k_update_seeds
-    if (s < 0) return;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
-    stamp(c, 3, s, 0, lane);
-    const Intrinsics K = c->k;
-    const double hr = c->huber;
-    const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
-    const float4 core = c->core[s];
+    const int x = blk.x * 64 + (threadIdx.x & 63), y = blk.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const unsigned p = (unsigned)(__mul24(y, pitch) + x), p4 = p << 2;
+    const float d = ld_off(dep, p4);
+    const int l = ld_off(c->label, p4);
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    const bool interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2; // FF.cpp:670-677
+    if (l >= 0 && interior && d > flt_below(0.05)) {                   // (double)d > 0.05
+        const float md = ld_off(reinterpret_cast<const float *>(c->core), ((unsigned)l << 4) + 12u);
+        const float d_right = ld_off(dep, p4 + 4u), d_down = ld_off(dep, p4 + ((unsigned)pitch << 2));
+        const float rx0 = ld_off(c->ray_x, (unsigned)x << 2), rx1 = ld_off(c->ray_x, ((unsigned)x << 2) + 4u);
+        const float ry0 = ld_off(c->ray_y, (unsigned)y << 2), ry1 = ld_off(c->ray_y, ((unsigned)y << 2) + 4u);
+        if (fabsf(md - d) < flt_above(c->huber)) pixel_normal_rays(rx0, rx1, ry0, ry1, d, d_right, d_down, nx, ny, nz);
+    }
+    float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(c->normals) + p * 12u);
+    o[0] = nx; o[1] = ny; o[2] = nz;
+}
+
+// k_seed_stats, ONE LANE PER SEED (64 consecutive seeds per wave): calculate_sp_depth_norms up to the plane fit's
+// starting point (FF.cpp:813-871) and the head of get_huber_norm (FF.cpp:111-120).  A lane walks its seed's 16x16 window
+// twice in row-major order: once over labels and depths (member count with depth, radius, depth inliers, the ordered
+// sums of their back-projected points), once over labels and the normal plane (ordered sum of the inliers' normals:
+// k_pixel_normals left zero wherever a pixel is not an inlier of its own superpixel, and a running sum that starts at
+// +0 is unchanged by adding +0).  The wave-per-seed form spent 611 VALU instructions per seed on this, most of them
+// per-seed bookkeeping and six-lane sums; a lane spends ~26 per window pixel for 64 seeds at once.
+struct StatRow { // one window row of one lane: labels and depths, or labels and normals
+    int4 lab[4];
+    float4 dp[4];
+};
+struct NormRow {
+    int4 lab[4];
+    float4 nv[12]; // 16 pixels x 3 floats
+};
+template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    const int lane = lane_id();
+    const int S = c->n_seed;
+    const int s = (((S + 63) >> 6) - 1 - blk.x) * 64 + lane; // bottom rows first, see seed_of_block
+    const bool live = s < S;
+    const int sc = live ? s : S - 1;
+    const FrameParams &fp = frame_params(c);
+    const float *dep = frame_depth(c, fp);
+    const int w = c->w, h = c->h, pitch = c->pitch;
     int gx, gy;
-    seed_cell(c, s, gx, gy);
+    seed_cell(c, sc, gx, gy);
     const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
-    float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2];
-    float *N0 = s_col[wv][3], *N1 = s_col[wv][4], *N2 = s_col[wv][5];
-    float *ld = P0;
-    int *lxy = reinterpret_cast<int *>(P1);
+    const float4 core = c->core[sc];
+    const float md = core.w;
+    const float hr_above = flt_above(c->huber); // the Huber class tests in fp32 (dsm_math.h)
+    const int s_match = live ? s : -2;          // no label is -2
+    int qx[4];                                  // window quads as pixel offsets within a row, redirected into the row (see k_update_seeds)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = wx0 + 4 * q;
+        qx[q] = x < 0 ? 0 : (x > pitch - 4 ? pitch - 4 : x);
+    }
+    bool col_in[kWin];
+    float exx[kWin], rx[kWin];
+#pragma unroll
+    for (int j = 0; j < kWin; j++) {
+        const int x = wx0 + j;
+        col_in[j] = (unsigned)x < (unsigned)w;
+        const float ex = (float)x - core.x;
+        exx[j] = ex * ex; // FF.cpp:820-823: the radius term of this column
+        rx[j] = ld_off(c->ray_x, (unsigned)(x < 0 ? 0 : (x > w ? w : x)) << 2);
+    }
+    auto row_offset = [&](int r) {
+        int y = wy0 + r;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        return (unsigned)__mul24(y, pitch);
+    };
 
-    // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
-    int n = 0;
-    float far2 = 0.0f;
-    int lab[4];
-    float pd[4];
-    const int x0 = wx0 + (lane & (kWin - 1)), y0 = wy0 + (lane >> 4);
-    const int key0 = __mul24(y0, pitch) + x0, row4 = 4 * pitch; // pixel keys as byte offsets: see ld_off
+    // ---- first walk: labels and depths
+    int n = 0, m_in = 0;
+    float far2 = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    auto load_a = [&](int r) {
+        StatRow R;
+        const unsigned row = row_offset(r);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { // 8 independent loads, one round trip
-        const int y = y0 + 4 * k;
-        const bool in = x0 >= 0 && x0 < w && y >= 0 && y < h;
-        const unsigned o4 = in ? (unsigned)(key0 + k * row4) << 2 : 0u;
-        const int l = ld_off(c->label, o4);
-        lab[k] = in ? l : -1;
-        pd[k] = ld_off(dep, o4);
-    }
+        for (int q = 0; q < 4; q++) {
+            const unsigned o4 = (row + (unsigned)qx[q]) << 2;
+            R.lab[q] = ld_vec<int4>(c->label, o4);
+            R.dp[q] = ld_vec<float4>(dep, o4);
+        }
+        return R;
+    };
+    auto walk_a = [&](const StatRow &A, int r) {
+        const int y = wy0 + r;
+        const bool row_in = (unsigned)y < (unsigned)h;
+        const int s_row = row_in ? s_match : -2;
+        const int yc = y < 0 ? 0 : (y > h ? h : y);
+        const float ry = ld_off(c->ray_y, (unsigned)yc << 2);
+        const float ey = (float)y - core.y, eyy = ey * ey;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = k * 64 + lane;
-        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
-        const bool mem = lab[k] == s;
-        float d = 0.0f;
-        if (mem) {
-            d = pd[k];
-            const float ex = (float)x - core.x, ey = (float)y - core.y;
-            const float d2 = ex * ex + ey * ey;
-            if (d2 > far2) far2 = d2;
-        }
-        const bool ok = mem && d > flt_below(0.05); // (double)d > 0.05
-        const unsigned long long m = __ballot(ok);
-        if (ok) {
-            const int pos = n + rank_below(m);
-            ld[pos] = d;
-            lxy[pos] = x | (y << 16);
-        }
-        n += __popcll(m);
-    }
-    far2 = wave_max(far2);
-    wave_lds_sync();
-    stamp(c, 3, s, 1, lane);
-
-    int m_fit = 0; // inliers handed to the fit; 0: the seed keeps its defaults
-    wave_priority(n); // long lists first: they are the kernel's critical path
-    if (n >= 16) { // FF.cpp:841
-        // ---- depth inliers: their pixel normals and back-projected points, in order (FF.cpp:846-861)
-        const float md = core.w;
-        int m_in = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            bool ok = false, interior = false;
-            float d = 0.0f, d_right = 0.0f, d_down = 0.0f;
-            int x = 0, y = 0;
-            if (i < n) {
-                d = ld[i];
-                const int xy = lxy[i];
-                x = xy & 0xffff; y = xy >> 16;
-                interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2; // FF.cpp:670-677
-                if (interior) { // neighbours for the forward differences, fetched before they are known to be needed
-                    const unsigned o4 = (unsigned)(__mul24(y, pitch) + x) << 2;
-                    d_right = ld_off(dep, o4 + 4u);
-                    d_down = ld_off(dep, o4 + ((unsigned)pitch << 2));
-                }
-                const float r = md - d;
-                ok = fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
+        for (int j = 0; j < kWin; j++) {
+            const bool mem = comp(A.lab[j >> 2], j & 3) == s_row && col_in[j];
+            const float d2 = exx[j] + eyy;
+            far2 = fmaxf(far2, mem ? d2 : 0.0f);               // FF.cpp:820-824, over all members
+            const float d = comp(A.dp[j >> 2], j & 3);
+            const bool ok = mem && d > flt_below(0.05);        // (double)d > 0.05
+            n += ok ? 1 : 0;
+            const bool inl = ok && fabsf(md - d) < hr_above;    // (double)r < hr && (double)r > -hr
+            m_in += inl ? 1 : 0;
+            sx += inl ? rx[j] * d : 0.0f;                       // back_project (FF.cpp:91-97), summed in window order (FF.cpp:111-116)
+            sy += inl ? ry * d : 0.0f;
+            sz += inl ? d : 0.0f;
+            if ((j & 3) == 3) {
+                asm volatile("" : "+v"(n), "+v"(m_in), "+v"(far2), "+v"(sx), "+v"(sy), "+v"(sz)); // see k_update_seeds
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int pos = m_in + rank_below(m);
-                float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-                if (interior) pixel_normal(K, x, y, d, d_right, d_down, nx, ny, nz);
-                N0[pos] = nx; N1[pos] = ny; N2[pos] = nz;
-                float px, py, pz;
-                back_project(K, (float)x, (float)y, d, px, py, pz);
-                P0[pos] = px; P1[pos] = py; P2[pos] = pz;
-            }
-            m_in += __popcll(m);
         }
-        // pad every column the ordered sums stream to a multiple of 16 with +0.0f (see ordered_sum)
-        wave_lds_sync();
-        pad_column(P0, m_in, lane); pad_column(P1, m_in, lane); pad_column(P2, m_in, lane);
-        pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
-        wave_lds_sync();
-        stamp(c, 3, s, 2, lane);
-        if (m_in > kGnCap) {
-            // more inliers than a superpixel can have (15 x 15 = 225 members): the label image did not come from
-            // k_assign (dsm_debug_set_label_buffer).  The hand-off to the fit holds kGnCap points: report, no fit.
-            if (lane == 0) atomicOr(c->status, kStatusBadLabels);
-        } else if (!((float)m_in / (float)n < flt_above(0.8))) { // FF.cpp:862, (double)ratio < 0.8
-            // sequential fp32 sums, FF.cpp:852-857 and 111-116
-            // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
-            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in);
-            float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2);
-            float mx = __shfl(part, 3), my = __shfl(part, 4), mz = __shfl(part, 5);
-            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
-            nx = nx / len; ny = ny / len; nz = nz / len;
-            mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
-            // centred points, FF.cpp:121-126
-            float *pts = c->gn_pts + (int64_t)s * 3 * kGnCap;
+    };
+    {
+        StatRow B0 = load_a(0), B1 = load_a(1), B2 = load_a(2), B3;
+#pragma unroll 1
+        for (int r = 0; r < kWin; r += 4) {
+            B3 = load_a(r + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_a(B0, r);
+            if (r + 4 < kWin) B0 = load_a(r + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_a(B1, r + 1);
+            if (r + 4 < kWin) B1 = load_a(r + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_a(B2, r + 2);
+            if (r + 4 < kWin) B2 = load_a(r + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_a(B3, r + 3);
+        }
+    }
+    // does this seed get a plane at all?  FF.cpp:841 (>= 16 members with depth), FF.cpp:862 (>= 80 % of them inliers)
+    bool fit = live && n >= 16 && !((float)m_in / (float)n < flt_above(0.8)); // (double)ratio < 0.8
+    if (fit && m_in > kGnCap) { // more inliers than a superpixel can have: the label image did not come from k_assign
+        atomicOr(c->status, kStatusBadLabels);
+        fit = false;
+    }
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    if (__ballot(fit) != 0) {
+        // ---- second walk: labels and normals
+        auto load_b = [&](int r) {
+            NormRow R;
+            const unsigned row = row_offset(r);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i = k * 64 + lane;
-                if (i < m_in) {
-                    pts[i] = P0[i] - mx;
-                    pts[kGnCap + i] = P1[i] - my;
-                    pts[2 * kGnCap + i] = P2[i] - mz;
+            for (int q = 0; q < 4; q++) {
+                const unsigned o = row + (unsigned)qx[q];
+                R.lab[q] = ld_vec<int4>(c->label, o << 2);
+#pragma unroll
+                for (int t = 0; t < 3; t++) R.nv[3 * q + t] = ld_vec<float4>(c->normals, o * 12u + 16u * t);
+            }
+            return R;
+        };
+        auto walk_b = [&](const NormRow &A, int r) {
+            const int y = wy0 + r;
+            const int s_row = (r < kWin && (unsigned)y < (unsigned)h) ? s_match : -2;
+#pragma unroll
+            for (int j = 0; j < kWin; j++) {
+                const bool mem = comp(A.lab[j >> 2], j & 3) == s_row && col_in[j];
+                const int e = 3 * (j & 3); // the pixel's three floats within its quad's twelve
+                nx += mem ? comp(A.nv[3 * (j >> 2) + (e >> 2)], e & 3) : 0.0f;
+                ny += mem ? comp(A.nv[3 * (j >> 2) + ((e + 1) >> 2)], (e + 1) & 3) : 0.0f;
+                nz += mem ? comp(A.nv[3 * (j >> 2) + ((e + 2) >> 2)], (e + 2) & 3) : 0.0f;
+                if ((j & 3) == 3) {
+                    asm volatile("" : "+v"(nx), "+v"(ny), "+v"(nz));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (lane == 0) {
-                GnHeader hd;
-                hd.m_in = m_in;
-                hd.nx = nx; hd.ny = ny; hd.nz = nz;
-                hd.mx = mx; hd.my = my; hd.mz = mz;
-                hd.far2 = far2;
-                c->gn_hdr[s] = hd;
-            }
-            m_fit = m_in;
+        };
+        NormRow B0 = load_b(0), B1 = load_b(1), B2;
+#pragma unroll 1
+        for (int r = 0; r < kWin; r += 3) { // 18 rows: the two past the window are clamped re-reads, masked by their row test
+            B2 = load_b(r + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_b(B0, r);
+            B0 = load_b(r + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_b(B1, r + 1);
+            B1 = load_b(r + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            walk_b(B2, r + 2);
         }
     }
-    if (m_fit == 0 && lane == 0) c->gn_hdr[s].m_in = 0;
-    stamp(c, 3, s, 5, lane);
-    if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
+    if (!live) return;
+    GnHeader hd;
+    hd.m_in = 0;
+    hd.nx = hd.ny = hd.nz = hd.mx = hd.my = hd.mz = 0.0f;
+    hd.far2 = far2;
+    if (fit) {
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz); // FF.cpp:866-871
+        hd.nx = nx / len; hd.ny = ny / len; hd.nz = nz / len;
+        hd.mx = sx / (float)m_in; hd.my = sy / (float)m_in; hd.mz = sz / (float)m_in; // FF.cpp:117-120
+        hd.m_in = m_in;
+    }
+    c->gn_hdr[s] = hd;
 }
 
 // ---- the fit: four seeds per wave, sixteen lanes per seed
@@ -1237,16 +1292,6 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
         core = c->core[s];
         is_stable = c->tmin[s] == kIntMax ? 1 : 0;
     }
-    // the first 64 points of every list are fetched before the list lengths are known (one dependent round trip
-    // less for the half of the groups whose lists are no longer than that; a kernel starts with a cold L2)
-    float4 head[kFitSeeds][3];
-#pragma unroll
-    for (int q = 0; q < kFitSeeds; q++) {
-        const float *pts = c->gn_pts + (int64_t)(s0 + q < S ? s0 + q : S - 1) * 3 * kGnCap;
-#pragma unroll
-        for (int col = 0; col < 3; col++)
-            head[q][col] = lane < 16 ? *reinterpret_cast<const float4 *>(pts + col * kGnCap + lane * 4) : make_float4(0, 0, 0, 0);
-    }
     const int m = hd.m_in;
     int mg[kFitSeeds];
 #pragma unroll
@@ -1263,24 +1308,64 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     stamp(c, 4, s0, 1, lane);
 
     if (m_max > 0) {
-        // ---- lists into LDS: p columns from k_seed_points' hand-off, zeroed residuals, all padded to m8
+        // ---- lists into LDS: the columns zeroed up to m8, then the sixteen lanes of a seed gather its centred inlier points,
+        // one window row each, in window row-major order (FF.cpp:846-861, 121-126: the points k_seed_stats summed)
         if (lane < 8) s_ones[lane] = 1.0f;
-#pragma unroll
-        for (int q = 0; q < kFitSeeds; q++) {
-            const float *pts = c->gn_pts + (int64_t)(s0 + q < S ? s0 + q : S - 1) * 3 * kGnCap;
+        {
             const int i4 = lane * 4; // m8 <= 232: one 16-byte chunk per lane and column
             if (i4 < m8) {
 #pragma unroll
-                for (int col = 0; col < 3; col++) {
-                    float4 v = head[q][col];
-                    if (i4 >= 64) v = i4 < mg[q] ? *reinterpret_cast<const float4 *>(pts + col * kGnCap + i4) : make_float4(0, 0, 0, 0);
-                    if (i4 >= mg[q]) v.x = 0.0f;
-                    if (i4 + 1 >= mg[q]) v.y = 0.0f;
-                    if (i4 + 2 >= mg[q]) v.z = 0.0f;
-                    if (i4 + 3 >= mg[q]) v.w = 0.0f;
-                    *reinterpret_cast<float4 *>(&s_col[q][col][i4]) = v;
+                for (int q = 0; q < kFitSeeds; q++)
+#pragma unroll
+                    for (int col = 0; col < kFitCols; col++) *reinterpret_cast<float4 *>(&s_col[q][col][i4]) = make_float4(0, 0, 0, 0);
+            }
+        }
+        wave_lds_sync();
+        if (m > 0) {
+            const float *dep = frame_depth(c, fp);
+            const int w = c->w, h = c->h, pitch = c->pitch;
+            int gx, gy;
+            seed_cell(c, s, gx, gy);
+            const int wx0 = gx * kCell + kCell / 2 - kCell, y = gy * kCell + kCell / 2 - kCell + gl;
+            const bool row_in = (unsigned)y < (unsigned)h;
+            const unsigned row = (unsigned)__mul24(y < 0 ? 0 : (y > h - 1 ? h - 1 : y), pitch);
+            const float ry = ld_off(c->ray_y, (unsigned)(y < 0 ? 0 : (y > h ? h : y)) << 2);
+            int4 lab[4];
+            float4 dp[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { // window quads redirected into the row where they leave it (masked below)
+                const int xq = wx0 + 4 * q;
+                const unsigned o4 = (row + (unsigned)(xq < 0 ? 0 : (xq > pitch - 4 ? pitch - 4 : xq))) << 2;
+                lab[q] = ld_vec<int4>(c->label, o4);
+                dp[q] = ld_vec<float4>(dep, o4);
+            }
+            const float md = core.w;
+            unsigned inl = 0; // this row's inliers, bit j = window column j
+#pragma unroll
+            for (int j = 0; j < kWin; j++) {
+                const float d = comp(dp[j >> 2], j & 3);
+                const bool ok = row_in && (unsigned)(wx0 + j) < (unsigned)w && comp(lab[j >> 2], j & 3) == s && d > flt_below(0.05) &&
+                                fabsf(md - d) < hr_above;
+                inl |= ok ? 1u << j : 0u;
+            }
+            // where this row's points start in the seed's list: exclusive prefix of the row counts over the group's 16 lanes
+            const int cnt = __popc(inl);
+            int pre = cnt;
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, false); // row_shr:1 .. 8: Hillis-Steele within the row of 16
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, false);
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, false);
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, false);
+            int pos = pre - cnt;
+#pragma unroll
+            for (int j = 0; j < kWin; j++) {
+                if ((inl >> j) & 1u) {
+                    const float d = comp(dp[j >> 2], j & 3);
+                    const int xc = wx0 + j; // in [0, w) for an inlier
+                    s_col[g][0][pos] = ld_off(c->ray_x, (unsigned)xc << 2) * d - hd.mx;
+                    s_col[g][1][pos] = ry * d - hd.my;
+                    s_col[g][2][pos] = d - hd.mz;
+                    pos++;
                 }
-                *reinterpret_cast<float4 *>(&s_col[q][3][i4]) = make_float4(0, 0, 0, 0);
             }
         }
         // per-lane rows of the tabled 4x4 inverse (dsm_math.h, kInv4)
@@ -2159,6 +2244,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     const dim3 g_seed_lane((S + 63) / 64); // one lane per seed
     const dim3 g_seed_rest((S + 63) / 64 + kRestOverBlocks); // packed queue entries, then the seeds with oversized lists
     const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
+    const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
     hipLaunchStage(k_init_seeds<false>, k_init_seeds<true>, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256));
@@ -2190,7 +2276,8 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
         hipLaunchStage(k_commit_seeds<false>, k_commit_seeds<true>, g_seed_thr, dim3(256), sweep);
         DSM_MARK();
     }
-    hipLaunchStage(k_seed_points<false>, k_seed_points<true>, g_seed_wave, dim3(256));
+    hipLaunchStage(k_pixel_normals<false>, k_pixel_normals<true>, g_pix4, dim3(256));
+    hipLaunchStage(k_seed_stats<false>, k_seed_stats<true>, g_seed_lane, dim3(64));
     DSM_MARK();
     hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitSmall>), dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
     if (batched) hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitLarge>), dim3(kFitLargeBlocks), dim3(64));

@@ -271,6 +271,31 @@ DSM_HD void back_project(const Intrinsics &k, float u, float v, float d, float &
     z = d;
 }
 
+// (u - cx) / fx of back_project for an integer pixel column (row: cy, fy): a property of the column, tabulated once per
+// handle (`ray_x[x]`, `ray_y[y]`) -- the correctly rounded fp32 divide is ten instructions, and the normal of one pixel needs
+// eight of them.  back_project(k, x, y, d) == (ray_x[x] * d, ray_y[y] * d, d), operation for operation.
+DSM_HD float ray_coeff(int u, float c, float f) { return ((float)u - c) / f; }
+
+// per-pixel normal from forward differences, FF.cpp:664-712, from the ray coefficients of columns x, x+1 and rows y, y+1.
+// Returns false (normal stays 0) when rejected.
+DSM_HD bool pixel_normal_rays(float rx0, float rx1, float ry0, float ry1, float d, float d_right, float d_down, float &nx, float &ny,
+                              float &nz) {
+    constexpr float kMin = flt_above(0.1); // (double)d < 0.1
+    if (d < kMin || d_right < kMin || d_down < kMin) return false;
+    const float px = rx0 * d, py = ry0 * d, pz = d;
+    float rx = rx1 * d_right, ry = ry0 * d_right, rz = d_right;
+    float dx = rx0 * d_down, dy = ry1 * d_down, dz = d_down;
+    rx = rx - px; ry = ry - py; rz = rz - pz;
+    dx = dx - px; dy = dy - py; dz = dz - pz;
+    float ax = ry * dz - rz * dy, ay = rz * dx - rx * dz, az = rx * dy - ry * dx;
+    float len = sqrtf(ax * ax + ay * ay + az * az);
+    ax /= len; ay /= len; az /= len;
+    float va = (ax * px + ay * py + az * pz) / sqrtf(px * px + py * py + pz * pz);
+    if (fabsf(va) < flt_above(kAngleCos)) return false; // (double)va > -kAngleCos && (double)va < kAngleCos
+    nx = ax; ny = ay; nz = az;
+    return true;
+}
+
 // per-pixel normal from forward differences, FF.cpp:664-712.  Caller guarantees
 // 1 <= x <= w-2 and 1 <= y <= h-2; returns false (normal stays 0) when rejected.
 DSM_HD bool pixel_normal(const Intrinsics &k, int x, int y, float d, float d_right, float d_down, float &nx,

@@ -209,10 +209,13 @@ void seed_planes(Emu &e) {
                 if (!(fabsf(r) < flt_above(e.huber))) continue;
                 float nx = 0, ny = 0, nz = 0;
                 const int x = lx[i], y = ly[i];
+                // (the kernels' form: tabulated ray coefficients per column / row, dsm_math.h ray_coeff)
+                const float rx0 = ray_coeff(x, e.K.cx, e.K.fx), rx1 = ray_coeff(x + 1, e.K.cx, e.K.fx);
+                const float ry0 = ray_coeff(y, e.K.cy, e.K.fy), ry1 = ray_coeff(y + 1, e.K.cy, e.K.fy);
                 if (x >= 1 && x <= e.w - 2 && y >= 1 && y <= e.h - 2)
-                    pixel_normal(e.K, x, y, ld[i], e.D(x + 1, y), e.D(x, y + 1), nx, ny, nz);
+                    pixel_normal_rays(rx0, rx1, ry0, ry1, ld[i], e.D(x + 1, y), e.D(x, y + 1), nx, ny, nz);
                 ln[m * 3] = nx; ln[m * 3 + 1] = ny; ln[m * 3 + 2] = nz;
-                back_project(e.K, (float)x, (float)y, ld[i], lp[m * 3], lp[m * 3 + 1], lp[m * 3 + 2]);
+                lp[m * 3] = rx0 * ld[i]; lp[m * 3 + 1] = ry0 * ld[i]; lp[m * 3 + 2] = ld[i];
                 m++;
             }
             if (!((float)m / (float)n < flt_above(0.8))) {
