@@ -791,6 +791,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.first_empty, (size_t)kSweeps * kWorkers));
         CREATE_TRY(dev_alloc(h, &q.gn_hdr, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.normals, (size_t)c.slot_elems * 3));
+        CREATE_TRY(dev_alloc(h, &q.plane, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.seeds, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_rec, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_ok, (size_t)c.n_seed));

@@ -165,6 +165,7 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DSM_G(rest_list);
     DSM_G(gn_hdr);
     DSM_G(normals);
+    DSM_G(plane);
     DSM_G(seeds);
     DSM_G(spawn_rec);
     DSM_G(spawn_ok);
@@ -289,7 +290,10 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
 // once per thread), a 64x16-pixel tile per block; the <=10x4 seeds a tile can pick from are staged in LDS.  FIRST sweep:
 // every pixel is evaluated (all labels 0, seed 0 unstable) so the pick is the label.  Later sweeps: the pick goes to
 // `cand`, and the sequential skip rule is resolved through tmin (see k_resolve).
-constexpr int kTileW = 64, kColumn = 4, kTileH = 4 * kColumn, kTileCellsX = kTileW / kCell + 2, kTileCellsY = kTileH / kCell + 2;
+constexpr int kTileW = 64, kTileCellsX = kTileW / kCell + 2;
+template <int COLS> struct AssignTile { // COLS pixels per thread: 4 in launches batched over many handles, 1 where latency counts
+    static constexpr int kH = 4 * COLS, kCellsY = (kH + kCell - 1) / kCell + 2;
+};
 
 // The reference scans pixels in row-major order; a pixel is skipped iff its current seed is still
 // `stable` when the scan reaches it, and every evaluated pixel clears `stable` of the seed it
@@ -316,7 +320,8 @@ __device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
     }
 }
 
-template <bool FIRST, bool BATCH> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) void k_assign(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    constexpr int kColumn = COLS, kTileH = AssignTile<COLS>::kH, kTileCellsY = AssignTile<COLS>::kCellsY;
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
@@ -883,6 +888,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
 // floats per element).  The workgroups after them: seeds whose list did not fit an LDS row, gathered and refined from
 // scratch by one wave each.
 constexpr int kRestOverBlocks = 32;
+constexpr int kLaneBatch = 8; // handles per launch from which the lane-per-seed kernels are used (launch_frame)
 template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds_rest(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
@@ -919,16 +925,20 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     if (live) c->core_stage[s].w = md;
 }
 
-// One wave per seed for ALL seeds: the launch for a single handle, where what counts is the kernel's latency -- it ends
-// with its slowest wave (~20 us), the lane-per-seed pair above with the slowest of its two stages each (~45 us) -- and
-// not the instructions issued, which is what bounds launches batched over several handles.  Same results, bit for bit.
-template <bool APPLY> __global__ __launch_bounds__(256) void k_update_seeds_wave(const DeviceCtx ctx, const DeviceCtx *__restrict__, int sweep) {
-    const DeviceCtx *__restrict__ c = &ctx;
+// One wave per seed for ALL seeds: the launch for one handle or a few (frame groups), where what counts is the kernel's
+// latency -- it ends with its slowest wave (~20 us), the lane-per-seed pair above with the slowest of its two stages each
+// (~45 us) -- and not the instructions issued, which is what bounds launches batched over many handles (kLaneBatch).
+// Same results, bit for bit.
+template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds_wave(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ __attribute__((aligned(16))) float s_depth[4][kWin * kWin];
     __shared__ __attribute__((aligned(16))) float s_term[4][kWin * kWin];
     const int wv = threadIdx.x >> 6;
     // (one seed per wave: the index lives in a scalar register, and so does every address formed from it)
-    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blockIdx.x, wv, c->gw, c->gh));
+    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh));
     if (s < 0) return;
     update_seed_wave<APPLY, true>(c, sweep, s, s_depth[wv], s_term[wv]);
 }
@@ -969,6 +979,158 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_commit_seeds(cons
 // i.e. (double)((2*X)*Y) with per-lane operand columns X, Y out of {p0, p1, p2, 1, r}: 14 lanes of a 16-lane group
 // each carry one, so four seeds fill the wave where one seed used 20 of 64 lanes (the Gauss-Newton steps were 60 %
 // of the one-kernel form's time).  The 4x4 solve is one lane per 2x2 determinant / adjugate entry, again per group.
+// ---- seed statistics, one WAVE per seed: the launch form for one handle or a few (frame groups), where the kernel's
+// latency counts -- a wave gathers its window with 4 pixels per lane and ends in ~11 us; the lane-per-seed pair below
+// walks 256 pixels per lane (35-45 us) and pays only when thousands of seeds share a launch.  Same header out.
+// Gather the member pixels with valid depth (window row-major order), keep the depth inliers, recompute their
+// back-projections and forward-difference normals from the depth plane, sum normals and points in the reference's order:
+// operands are produced lane-parallel, parked in LDS as structure-of-arrays columns and block-fetched; the six fp32
+// sums are six lanes.
+constexpr int kCols = 6; // LDS columns per wave of k_seed_points, reused across phases:
+//   gather / inlier phase:  depth list | packed xy | -       | n0       | n1   | n2
+//   sums phase:             p0         | p1        | p2      | n0       | n1   | n2
+// (p0/p1 overwrite the depth/xy lists in place: a chunk's 64 entries are read before its compacted
+// entries, which land at or below the same indices, are written)
+// column stride: 260 floats shifts successive columns by 4 banks, so that lanes streaming different
+// columns at the same element offset (ds_read_b128) do not collide
+constexpr int kColStride = kWin * kWin + 4;
+
+template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    __shared__ __attribute__((aligned(16))) float s_col[4][kCols][kColStride];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh)); // scalar, see k_update_seeds
+    if (s < 0) return;
+    const FrameParams &fp = frame_params(c);
+    const float *dep = frame_depth(c, fp);
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    stamp(c, 3, s, 0, lane);
+    const double hr = c->huber;
+    const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
+    const float4 core = c->core[s];
+    int gx, gy;
+    seed_cell(c, s, gx, gy);
+    const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+    float *P0 = s_col[wv][0], *P1 = s_col[wv][1], *P2 = s_col[wv][2];
+    float *N0 = s_col[wv][3], *N1 = s_col[wv][4], *N2 = s_col[wv][5];
+    float *ld = P0;
+    int *lxy = reinterpret_cast<int *>(P1);
+
+    // ---- members with depth > 0.05, and the superpixel radius (FF.cpp:813-838)
+    int n = 0;
+    float far2 = 0.0f;
+    int lab[4];
+    float pd[4];
+    const int x0 = wx0 + (lane & (kWin - 1)), y0 = wy0 + (lane >> 4);
+    const int key0 = __mul24(y0, pitch) + x0, row4 = 4 * pitch; // pixel keys as byte offsets: see ld_off
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // 8 independent loads, one round trip
+        const int y = y0 + 4 * k;
+        const bool in = x0 >= 0 && x0 < w && y >= 0 && y < h;
+        const unsigned o4 = in ? (unsigned)(key0 + k * row4) << 2 : 0u;
+        const int l = ld_off(c->label, o4);
+        lab[k] = in ? l : -1;
+        pd[k] = ld_off(dep, o4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = k * 64 + lane;
+        const int x = wx0 + (idx & (kWin - 1)), y = wy0 + (idx >> 4);
+        const bool mem = lab[k] == s;
+        float d = 0.0f;
+        if (mem) {
+            d = pd[k];
+            const float ex = (float)x - core.x, ey = (float)y - core.y;
+            const float d2 = ex * ex + ey * ey;
+            if (d2 > far2) far2 = d2;
+        }
+        const bool ok = mem && d > flt_below(0.05); // (double)d > 0.05
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const int pos = n + rank_below(m);
+            ld[pos] = d;
+            lxy[pos] = x | (y << 16);
+        }
+        n += __popcll(m);
+    }
+    far2 = wave_max(far2);
+    wave_lds_sync();
+    stamp(c, 3, s, 1, lane);
+
+    int m_fit = 0; // inliers handed to the fit; 0: the seed keeps its defaults
+    wave_priority(n); // long lists first: they are the kernel's critical path
+    if (n >= 16) { // FF.cpp:841
+        // ---- depth inliers: their pixel normals and back-projected points, in order (FF.cpp:846-861)
+        const float md = core.w;
+        int m_in = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool ok = false, interior = false;
+            float d = 0.0f, d_right = 0.0f, d_down = 0.0f, rx0 = 0.0f, rx1 = 0.0f, ry0 = 0.0f, ry1 = 0.0f;
+            int x = 0, y = 0;
+            if (i < n) {
+                d = ld[i];
+                const int xy = lxy[i];
+                x = xy & 0xffff; y = xy >> 16;
+                interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2; // FF.cpp:670-677
+                if (interior) { // neighbours for the forward differences, fetched before they are known to be needed
+                    const unsigned o4 = (unsigned)(__mul24(y, pitch) + x) << 2;
+                    d_right = ld_off(dep, o4 + 4u);
+                    d_down = ld_off(dep, o4 + ((unsigned)pitch << 2));
+                }
+                rx0 = ld_off(c->ray_x, (unsigned)x << 2); rx1 = ld_off(c->ray_x, ((unsigned)x << 2) + 4u);
+                ry0 = ld_off(c->ray_y, (unsigned)y << 2); ry1 = ld_off(c->ray_y, ((unsigned)y << 2) + 4u);
+                const float r = md - d;
+                ok = fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = m_in + rank_below(m);
+                float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+                if (interior) pixel_normal_rays(rx0, rx1, ry0, ry1, d, d_right, d_down, nx, ny, nz);
+                N0[pos] = nx; N1[pos] = ny; N2[pos] = nz;
+                P0[pos] = rx0 * d; P1[pos] = ry0 * d; P2[pos] = d; // back_project, FF.cpp:91-97
+            }
+            m_in += __popcll(m);
+        }
+        // pad every column the ordered sums stream to a multiple of 16 with +0.0f (see ordered_sum)
+        wave_lds_sync();
+        pad_column(P0, m_in, lane); pad_column(P1, m_in, lane); pad_column(P2, m_in, lane);
+        pad_column(N0, m_in, lane); pad_column(N1, m_in, lane); pad_column(N2, m_in, lane);
+        wave_lds_sync();
+        stamp(c, 3, s, 2, lane);
+        if (m_in > kGnCap) {
+            // more inliers than a superpixel can have (15 x 15 = 225 members): the label image did not come from
+            // k_assign (dsm_debug_set_label_buffer).  The hand-off to the fit holds kGnCap points: report, no fit.
+            if (lane == 0) atomicOr(c->status, kStatusBadLabels);
+        } else if (!((float)m_in / (float)n < flt_above(0.8))) { // FF.cpp:862, (double)ratio < 0.8
+            // sequential fp32 sums, FF.cpp:852-857 and 111-116
+            // six ordered sums at once: lane q < 6 streams column q (n0 n1 n2 p0 p1 p2)
+            const float part = ordered_sum(s_col[wv][lane < 3 ? 3 + lane : lane < 6 ? lane - 3 : 0], m_in);
+            float nx = __shfl(part, 0), ny = __shfl(part, 1), nz = __shfl(part, 2);
+            float mx = __shfl(part, 3), my = __shfl(part, 4), mz = __shfl(part, 5);
+            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            nx = nx / len; ny = ny / len; nz = nz / len;
+            mx /= (float)m_in; my /= (float)m_in; mz /= (float)m_in;
+            if (lane == 0) {
+                GnHeader hd;
+                hd.m_in = m_in;
+                hd.nx = nx; hd.ny = ny; hd.nz = nz;
+                hd.mx = mx; hd.my = my; hd.mz = mz;
+                hd.far2 = far2;
+                c->gn_hdr[s] = hd;
+            }
+            m_fit = m_in;
+        }
+    }
+    if (m_fit == 0 && lane == 0) c->gn_hdr[s].m_in = 0;
+    stamp(c, 3, s, 5, lane);
+    if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
+}
+
 // ---- seed statistics without a wave per seed
 // k_pixel_normals, one thread per pixel: the forward-difference normal (FF.cpp:664-712) of every pixel that is a depth
 // inlier of its own superpixel (FF.cpp:846-850: member, depth > 0.05, |mean depth - depth| < HUBER_RANGE) and zero for
@@ -1280,17 +1442,14 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     const bool live = s < S;
     stamp(c, 4, s0, 0, lane);
     const FrameParams &fp = frame_params(c);
-    const Intrinsics K = c->k;
     const double hr = c->huber;
     const float hr_above = flt_above(hr); // the Huber class tests in fp32 (dsm_math.h)
     GnHeader hd;
     hd.m_in = 0;
     float4 core = make_float4(0, 0, 0, 0);
-    int is_stable = 0;
     if (live) {
         hd = c->gn_hdr[s];
         core = c->core[s];
-        is_stable = c->tmin[s] == kIntMax ? 1 : 0;
     }
     const int m = hd.m_in;
     int mg[kFitSeeds];
@@ -1482,8 +1641,25 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
 
     stamp(c, 4, s0, 4, lane);
     if (c->stamps && lane == 0) c->stamps[((int64_t)4 * c->n_seed + s0) * 8 + 7] = m_max;
-    // ---- seed record and the surfel it would create: one lane per seed
-    if (!live || gl != 0) return;
+    // ---- the fitted plane goes to k_seed_finish (the seed record and the surfel it would create are a few hundred
+    // double-typed instructions per seed: there a lane per seed, here they would run with 4 of 64 lanes)
+    if (live && gl == 0 && m > 0) c->plane[s] = make_float4(nx, ny, nz, nb);
+    if (g == 0) stamp(c, 4, s0, 5, lane);
+}
+
+// The seed record (FF.cpp:872-914: plane to normal / position / view angle) and the per-seed part of initialize_surfels
+// (FF.cpp:315-361, up to the `fused` test that k_frame_tail applies), one thread per seed.
+template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_finish(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    const int s = blk.x * 256 + threadIdx.x;
+    if (s >= c->n_seed) return;
+    const FrameParams &fp = frame_params(c);
+    const Intrinsics K = c->k;
+    const GnHeader hd = c->gn_hdr[s];
+    const float4 core = c->core[s];
     dsm_seed out;
     out.x = core.x; out.y = core.y;
     out.size = 0; out.norm_x = out.norm_y = out.norm_z = 0;
@@ -1492,10 +1668,12 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     out.mean_depth = core.w;
     out.mean_intensity = core.z;
     out.fused = 0;
-    out.stable = (uint8_t)is_stable;
+    out.stable = (uint8_t)(c->tmin[s] == kIntMax ? 1 : 0);
     out.pad_[0] = out.pad_[1] = 0;
     out.min_eigen_value = out.max_eigen_value = 0;
-    if (m > 0) {
+    if (hd.m_in > 0) {
+        const float4 pl = c->plane[s];
+        float nx = pl.x, ny = pl.y, nz = pl.z, nb = pl.w;
         plane_finish(nx, ny, nz, nb, hd.mx, hd.my, hd.mz);
         const SeedGeom sg = seed_geometry(K, core.x, core.y, core.w, nx, ny, nz, nb);
         out.norm_x = sg.nx; out.norm_y = sg.ny; out.norm_z = sg.nz;
@@ -1505,7 +1683,6 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
         out.size = sqrtf(hd.far2);
     }
     c->seeds[s] = out;
-    // initialize_surfels, FF.cpp:315-361, up to the `fused` test (k_frame_tail applies it)
     SeedView sd;
     sd.size = out.size; sd.nx = out.norm_x; sd.ny = out.norm_y; sd.nz = out.norm_z;
     sd.px = out.posi_x; sd.py = out.posi_y; sd.pz = out.posi_z;
@@ -1522,7 +1699,6 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     c->spawn_ok[s] = ok ? 1 : 0;
     c->fused_flag[s] = 0;
     c->seed_weight[s] = depth_weight(out.mean_depth); // FF.cpp:274: what a surfel fusing into this seed weighs it with
-    if (g == 0) stamp(c, 4, s0, 5, 0);
 }
 
 template <bool BATCH, int TIER> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
@@ -2243,7 +2419,12 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     const dim3 g_seed_wave((S + 3) / 4);
     const dim3 g_seed_lane((S + 63) / 64); // one lane per seed
     const dim3 g_seed_rest((S + 63) / 64 + kRestOverBlocks); // packed queue entries, then the seeds with oversized lists
-    const dim3 g_tile((hc.w + kTileW - 1) / kTileW, (hc.h + kTileH - 1) / kTileH);
+    // Two forms of the per-seed stages (same results): a wave per seed where the launch's latency counts -- one handle, or
+    // the few of a frame group -- and a lane per seed (and four pixels per thread in k_assign) where the instructions
+    // issued count: launches batched over kLaneBatch handles or more.
+    const bool lanes = batched && n_batch >= kLaneBatch;
+    const dim3 g_tile1((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<1>::kH - 1) / AssignTile<1>::kH);
+    const dim3 g_tile4((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<4>::kH - 1) / AssignTile<4>::kH);
     const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
@@ -2251,36 +2432,43 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
-            hipLaunchStage((k_assign<true, false>), (k_assign<true, true>), g_tile, dim3(256), sweep);
+            if (lanes) hipLaunchStage((k_assign<true, true, 4>), (k_assign<true, true, 4>), g_tile4, dim3(256), sweep);
+            else hipLaunchStage((k_assign<true, false, 1>), (k_assign<true, true, 1>), g_tile1, dim3(256), sweep);
             DSM_MARK();
-            if (batched) {
+            if (lanes) {
                 hipLaunchStage((k_update_seeds<false, true>), (k_update_seeds<false, true>), g_seed_lane, dim3(64), sweep);
                 hipLaunchStage((k_update_seeds_rest<false, true>), (k_update_seeds_rest<false, true>), g_seed_rest, dim3(64), sweep);
             } else {
-                hipLaunchStage(k_update_seeds_wave<false>, k_update_seeds_wave<false>, g_seed_wave, dim3(256), sweep);
+                hipLaunchStage((k_update_seeds_wave<false, false>), (k_update_seeds_wave<false, true>), g_seed_wave, dim3(256), sweep);
             }
             DSM_MARK();
         } else {
-            hipLaunchStage((k_assign<false, false>), (k_assign<false, true>), g_tile, dim3(256), sweep);
+            if (lanes) hipLaunchStage((k_assign<false, true, 4>), (k_assign<false, true, 4>), g_tile4, dim3(256), sweep);
+            else hipLaunchStage((k_assign<false, false, 1>), (k_assign<false, true, 1>), g_tile1, dim3(256), sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
             DSM_MARK();
-            if (batched) {
+            if (lanes) {
                 hipLaunchStage((k_update_seeds<true, true>), (k_update_seeds<true, true>), g_seed_lane, dim3(64), sweep);
                 hipLaunchStage((k_update_seeds_rest<true, true>), (k_update_seeds_rest<true, true>), g_seed_rest, dim3(64), sweep);
             } else {
-                hipLaunchStage(k_update_seeds_wave<true>, k_update_seeds_wave<true>, g_seed_wave, dim3(256), sweep);
+                hipLaunchStage((k_update_seeds_wave<true, false>), (k_update_seeds_wave<true, true>), g_seed_wave, dim3(256), sweep);
             }
             DSM_MARK();
         }
         hipLaunchStage(k_commit_seeds<false>, k_commit_seeds<true>, g_seed_thr, dim3(256), sweep);
         DSM_MARK();
     }
-    hipLaunchStage(k_pixel_normals<false>, k_pixel_normals<true>, g_pix4, dim3(256));
-    hipLaunchStage(k_seed_stats<false>, k_seed_stats<true>, g_seed_lane, dim3(64));
+    if (lanes) {
+        hipLaunchStage(k_pixel_normals<true>, k_pixel_normals<true>, g_pix4, dim3(256));
+        hipLaunchStage(k_seed_stats<true>, k_seed_stats<true>, g_seed_lane, dim3(64));
+    } else {
+        hipLaunchStage(k_seed_points<false>, k_seed_points<true>, g_seed_wave, dim3(256));
+    }
     DSM_MARK();
     hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitSmall>), dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
     if (batched) hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitLarge>), dim3(kFitLargeBlocks), dim3(64));
+    hipLaunchStage(k_seed_finish<false>, k_seed_finish<true>, g_seed_thr, dim3(256));
     DSM_MARK();
     // grid-stride over the map with as many workgroups as the device holds at once: with more, the ones that start
     // late run all their trips after the others have finished theirs (2 048 against 1 280 resident cost 76 instead of

@@ -42,7 +42,19 @@ Eigen::Matrix4f pose_from(const float *p) {
 }
 }  // namespace
 
+#ifdef DSM_ORACLE_EIGEN_PERTURB
+int dsm_eigen_ulps_f[16] = {0}, dsm_eigen_ulps_d[16] = {0};
+#endif
+
 extern "C" {
+
+#ifdef DSM_ORACLE_EIGEN_PERTURB
+// exposure study only (tools/eigen_exposure.py): ulps added to every element of Matrix4f::inverse() (FF.cpp:59) and
+// Matrix4d::inverse() (FF.cpp:176)
+void dsmref_set_eigen_perturb(const int *f16, const int *d16) {
+    for (int i = 0; i < 16; i++) { dsm_eigen_ulps_f[i] = f16 ? f16[i] : 0; dsm_eigen_ulps_d[i] = d16 ? d16[i] : 0; }
+}
+#endif
 
 void *dsmref_create(int w, int h, float fx, float fy, float cx, float cy, float far_d, float near_d) {
     RefHandle *r = new RefHandle();

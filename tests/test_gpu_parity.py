@@ -257,16 +257,18 @@ def test_batched_replay_matches_stepwise(mods):
     _compare_frame("after 24 frames", ff, orc, ff.map_download(), lo.astype(api.SURFEL_DTYPE))
 
 
-@pytest.mark.parametrize("fit_small_cap", [None, 40, 0])
-def test_batched_lockstep_replay(mods, fit_small_cap):
+@pytest.mark.parametrize("fit_small_cap,B", [(None, 5), (None, 8), (40, 9), (0, 5)])
+def test_batched_lockstep_replay(mods, fit_small_cap, B):
     """dsm_batch_*: five handles with five different scenes advance in lockstep, every kernel launched once for all of
     them (grid z = handle); each subsequence's map equals the oracle's for its own scene, and a handle used alone
     afterwards continues correctly.  Batched launches fit the seed planes in two tiers (short LDS columns for nearly
     all groups of seeds, a queue worked off by a full-length kernel for the rest); these scenes never fill the queue,
     so the runs with a lowered limit send most (40) or all (0) groups through it."""
     api, synth, ob = mods
+    # (batches of fewer than eight handles launch the per-seed stages with a wave per seed, from eight on with a lane per
+    # seed and four pixels per thread in the assignment: both forms are exercised)
     cam = synth.VGA_DRIVE
-    n, B = 14, 5
+    n = 14
     scenes = [synth.Scene(seed=200 + 7 * b, n_boxes=6 + b) for b in range(B)]
     handles, plans, frames = [], [], []
     for b in range(B):
