@@ -53,7 +53,9 @@ def stage_alg_bytes(stage, n, n_seed, m_avg, k_avg):
     return n_seed * 16
 
 
-# stage (position in the frame's launch sequence) -> kernel function, as rocprofv3 names them
+# stage (position in the frame's launch sequence) -> kernel function(s), as rocprofv3 names them.  Launches batched over
+# eight or more subsequences use the lane-per-seed forms of the per-seed stages (two or three kernels per stage), a single
+# subsequence the wave-per-seed forms.
 KERNEL_OF_STAGE = {
     "init_seeds": "k_init_seeds", "assign_0": "k_assign<true>", "assign_1": "k_assign<false>", "assign_2": "k_assign<false>",
     "resolve_1": "k_resolve", "resolve_2": "k_resolve",
@@ -61,29 +63,40 @@ KERNEL_OF_STAGE = {
     "commit_seeds_0": "k_commit_seeds", "commit_seeds_1": "k_commit_seeds", "commit_seeds_2": "k_commit_seeds",
     "seed_points": "k_seed_points", "seed_fit": "k_seed_fit", "fuse_surfels": "k_fuse_surfels", "frame_tail": "k_frame_tail",
 }
+BATCHED_KERNELS_OF_STAGE = {
+    "assign_0": ["k_assign<true, true, 4>"], "assign_1": ["k_assign<false, true, 4>"], "assign_2": ["k_assign<false, true, 4>"],
+    "update_seeds_0": ["k_update_seeds<false, true>", "k_update_seeds_rest<false, true>"],
+    "update_seeds_1": ["k_update_seeds<true, true>", "k_update_seeds_rest<true, true>"],
+    "update_seeds_2": ["k_update_seeds<true, true>", "k_update_seeds_rest<true, true>"],
+    "seed_points": ["k_pixel_normals<true>", "k_seed_stats<true>"],
+    "seed_fit": ["k_seed_fit<true, 1>", "k_seed_fit<true, 2>", "k_seed_finish<true>"],
+}
+PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r03_pmc_traffic.json", "r03_pmc_traffic_batched.json", "r03_pmc_sq_batch8.md"
 
 
-def pmc_traffic(stage, name="r02_pmc_traffic.json"):
-    """HBM-side bytes per launch of `stage` from the committed rocprofv3 --pmc passes of this round (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, tools/gpu_pmc.sh; the JSON records them with the calibration used).
-    Counters cannot be read from inside the run; None when no measurement is on file."""
-    for name in (name,):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
-        kernels = json.load(open(path)).get("kernels", {})
-        rec = kernels.get(stage)
-        if rec:
-            return rec["hbm_bytes_per_launch"], name
-    return None, None
+def pmc_traffic(kernels, name):
+    """HBM-side bytes per launch of the given kernel(s) (summed) from the committed rocprofv3 --pmc passes of this round
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, tools/gpu_pmc.sh; the JSON records them with the calibration
+    used).  Counters cannot be read from inside the run; None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    table = json.load(open(path)).get("kernels", {})
+    if isinstance(kernels, str):
+        kernels = [kernels]
+    recs = [table.get(k) for k in kernels]
+    if not recs or any(r is None for r in recs):
+        return None, None
+    return sum(r["hbm_bytes_per_launch"] for r in recs), name
 
 
-def valu_issue(fps_per_gpu):
-    """The roof that does bind this path: VALU instruction issue.  Wave-instructions per frame from the committed
-    rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r02_pmc_sq_batch8.md; the
-    counts are per launch, a frame launches k_assign / k_update_seeds / k_commit_seeds three times and k_resolve twice)
-    against what 1 024 SIMDs issue at one wave64 instruction per 4 cycles and 2.4 GHz.  None when no pass is on file."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_sq_batch8.md")
+def valu_issue(fps_per_gpu, clock_ghz=None):
+    """The roof that binds the batched superpixel stages: VALU instruction issue.  Wave-instructions per frame from the
+    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r03_pmc_sq_batch8.md;
+    the counts are per launch, a frame launches the sweep kernels two or three times) against what 1 024 SIMDs issue at one
+    wave64 instruction per 4 cycles.  clock_ghz: the shader clock sampled during the timed region (2.4 GHz assumed when it
+    could not be read).  None when no pass is on file."""
+    path = os.path.join(ROOT, "profiles", PMC_SQ_BATCHED)
     if not os.path.exists(path):
         return None
     per_launch = {}
@@ -102,14 +115,60 @@ def valu_issue(fps_per_gpu):
                 pass
     if not per_launch:
         return None
-    launches = {"k_assign<false, true>": 2, "k_update_seeds<true, true>": 2, "k_commit_seeds<true>": 3, "k_resolve<true>": 2}
+    twice = ("k_assign<false, true, 4>", "k_update_seeds<true, true>", "k_update_seeds_rest<true, true>", "k_resolve<true>")
+    launches = {k: 2 for k in twice}
+    launches["k_commit_seeds<true>"] = 3
     per_frame = sum(v * launches.get(k, 1) for k, v in per_launch.items() if not k.startswith("k_repack")) / 8.0
-    peak = 256 * 4 * 2.4e9 / 4.0
-    return {"valu_wave_insts_per_frame": round(per_frame), "peak_wave_insts_per_s": peak,
+    ghz = clock_ghz or 2.4
+    peak = 256 * 4 * ghz * 1e9 / 4.0
+    return {"valu_wave_insts_per_frame": round(per_frame), "peak_wave_insts_per_s": peak, "shader_clock_ghz": ghz,
+            "shader_clock_source": "sampled during the timed region" if clock_ghz else "assumed (no clock sample available)",
             "frames_per_s_at_peak": round(peak / per_frame, 1), "frac": round(fps_per_gpu * per_frame / peak, 4),
-            "source": "profiles/r02_pmc_sq_batch8.md (rocprofv3 --pmc SQ_INSTS_VALU, launches batched over 8 subsequences)",
-            "note": "every instruction priced at the fp32 rate; the float<->double conversions of the mixed-precision "
-                    "expressions issue at a quarter of it (profiles/r02_issue_rates.md)"}
+            "source": f"profiles/{PMC_SQ_BATCHED} (rocprofv3 --pmc SQ_INSTS_VALU, launches batched over 8 subsequences)",
+            "note": "every instruction priced at the fp32 rate; float<->double conversions issue at a quarter of it, and a wave "
+                    "alone on its SIMD (the lane-per-seed kernels) issues one instruction per ~5.5 cycles, not 4"}
+
+
+class ClockSampler:
+    """Shader clock during the timed region: a thread reads the current sclk from sysfs (pp_dpm_sclk marks the active level
+    with '*') every 20 ms.  None if the file is not there (no amdgpu sysfs in the container)."""
+
+    def __init__(self):
+        import glob
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples, self._stop, self._thr = [], False, None
+
+    def _read(self):
+        for f in self.files[:1]:
+            try:
+                for line in open(f):
+                    if "*" in line:
+                        return float(line.split(":")[1].strip().lower().replace("mhz", "").replace("*", "").strip())
+            except (OSError, ValueError, IndexError):
+                return None
+        return None
+
+    def __enter__(self):
+        if self.files:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(0.02)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._thr:
+            self._thr.join()
+
+    def ghz(self):
+        return round(float(np.median(self.samples)) / 1e3, 3) if self.samples else None
 
 
 def cpu_model():
@@ -351,9 +410,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clock = ClockSampler()
     t0 = time.perf_counter()
-    run(lo_t, hi_t)
-    sync_all()
+    with clock:
+        run(lo_t, hi_t)
+        sync_all()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -449,7 +510,7 @@ def main():
         dom_us = float(np.mean([per[x] for x in dom_stages]))
         alg = float(np.mean([stage_alg_bytes(x, n_pix, n_seed, mt, k_avg) for x in dom_stages]))
         achieved = alg / (dom_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic(dom_fn)
+        traffic, traffic_src = pmc_traffic(dom_fn, PMC_TRAFFIC_SINGLE)
         out["roofline"] = {"bound": "hbm", "kernel": dom_fn, "launches_per_frame": len(dom_stages),
                            "share_of_frame_kernel_time": round(sum(per[x] for x in dom_stages) / sum(per.values()), 3),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -489,11 +550,11 @@ def main():
             dom_usb = float(np.mean([perb[x] for x in dom_stages]))
             algb = nb * float(np.mean([stage_alg_bytes(x, n_pix, n_seed, mtb, kb) for x in dom_stages]))
             achb = algb / (dom_usb * 1e-6) / 1e9
-            # (batched instantiations carry a second template argument: k_update_seeds<true> -> k_update_seeds<true, true>)
-            fn_b = dom_fn[:-1] + ", true>" if dom_fn.endswith(">") else dom_fn + "<true>"
-            traffic_b, traffic_src_b = pmc_traffic(fn_b, "r02_pmc_traffic_batched.json") if nb == 8 else (None, None)
+            # (a batched stage may be two or three kernels: the lane-per-seed forms)
+            fn_b = BATCHED_KERNELS_OF_STAGE.get(dom_stages[-1]) or [dom_fn[:-1] + ", true>" if dom_fn.endswith(">") else dom_fn + "<true>"]
+            traffic_b, traffic_src_b = pmc_traffic(fn_b, PMC_TRAFFIC_BATCHED) if nb == 8 else (None, None)
             out["roofline_single_launch"] = out["roofline"]
-            out["roofline"] = {"bound": "hbm", "kernel": dom_fn, "launches_per_frame": len(dom_stages), "subsequences_per_launch": nb,
+            out["roofline"] = {"bound": "hbm", "kernel": " + ".join(fn_b), "stage": dom_fn, "launches_per_frame": len(dom_stages), "subsequences_per_launch": nb,
                                "achieved": round(achb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achb / HBM_PEAK_GBS, 5),
                                "traffic": traffic_b,
                                "traffic_source": (f"profiles/{traffic_src_b} (rocprofv3 --pmc of launches batched over 8 subsequences, separate passes)"
@@ -599,8 +660,32 @@ def main():
                          "timing": "HIP events around 50 back-to-back dsm_map_warp calls on the handle's stream; the 172 MB "
                                    "array fits the 256 MB Infinity Cache, see map_warp_8M for the HBM-bound size"},
         }
+        # ... and the per-frame fuse against a map the Infinity Cache cannot hold (8 M live surfels: 352 MB in, <= 352 MB out)
+        big8 = np.tile(base, max(1, -(-8_000_000 // max(len(base), 1))))
+        for f in ("px", "py", "pz"):
+            big8[f] += rng.normal(scale=1e-3, size=len(big8)).astype(np.float32)
+        big8["update_times"] = 9
+        big8["last_update"] = 2
         ff.close()
-        # the same kernel on a working set the Infinity Cache cannot hold: 8 M surfels = 352 MB read + 352 MB written
+        ff = api.FusionFunctions.from_camera(cam_h, device=device, frame_slots=10, surfel_capacity=len(big8) + 600_000, pipeline_depth=1)
+        for i, (img, dep) in enumerate(frames_h):
+            ff.frame_upload(i, img, dep)
+        ff.map_upload(big8)
+        del big8
+        ff.replay_enqueue(plan_h[0][10:14], plan_h[1][10:14], plan_h[2][10:14])
+        ff.synchronize()
+        st_8, _ = ff.replay_timed(plan_h[0][40:48], plan_h[1][40:48], plan_h[2][40:48])
+        ovh_8 = ff.event_overhead_ms * 1e3
+        us_f8 = max(st_8["fuse_surfels"][0] / max(st_8["fuse_surfels"][1], 1) * 1e3 - ovh_8, 1e-3)
+        us_t8 = max(st_8["frame_tail"][0] / max(st_8["frame_tail"][1], 1) * 1e3 - ovh_8, 1e-3)
+        m_8 = ff.timed_mean_local
+        out["fuse_8M"] = {"workload": "1920x1080 frame fused into a live map of >= 8 M surfels (beyond the 256 MB Infinity Cache)",
+                          "live_surfels": round(m_8), "fuse_surfels_us": round(us_f8, 1), "alg_bytes": int(88 * m_8),
+                          "achieved_GBps": round(88 * m_8 / us_f8 / 1e3, 1), "hbm_frac": round(88 * m_8 / us_f8 / 1e3 / HBM_PEAK_GBS, 4),
+                          "frame_tail_us": round(us_t8, 1),
+                          "timing": "HIP events around the kernel on the handle's stream (eager replay, 8 frames)"}
+        ff.close()
+        # the warp kernel on a working set the Infinity Cache cannot hold: 8 M surfels = 352 MB read + 352 MB written
         n_w = 8_000_000
         wm = np.zeros(n_w, api.SURFEL_DTYPE)
         wm["px"] = np.arange(n_w, dtype=np.float32) * 1e-3
@@ -657,6 +742,54 @@ def main():
                                          "loop closure with warp of active and inactive surfels at frame %d); host-inclusive" % period}
         node.close()
 
+    if extras and args.mode == "batched":
+        # The headline replay never lets a keyframe leave the window, so its maps grow without bound and 83 % of B_alg is
+        # the 88 B/surfel map term.  The node keeps the surfels of the ~10 drift-free keyframes active (SM.cpp:154,
+        # 1456-1595: move_add_surfels): the same batched replay with every handle's keyframes older than 10 moved to its
+        # inactive store between steps (untimed: the node does it on the host's schedule) keeps M near 70 k.
+        hs = [make_handle(b, pipeline_depth=1) for b in range(B)]
+        bts = [api.Batch([hs[b] for b in grp]) for grp in groups_b]
+        next_key = [0] * B
+        k_b, w_b = min(K, 10), 3
+
+        def trim(t_first):
+            for b in range(B):
+                last = t_first // 5 - 10
+                while next_key[b] <= last:
+                    hs[b].store_deactivate(next_key[b])
+                    next_key[b] += 1
+
+        def step_b(i):
+            lo, hi = i * F, (i + 1) * F
+
+            def one(g):
+                sb, rb, pb, nn = api.Batch.pack([(plans[b][0][lo:hi], plans[b][1][lo:hi], plans[b][2][lo:hi]) for b in groups_b[g]])
+                bts[g].replay_enqueue(sb, rb, pb, nn)
+            list(pool.map(one, range(n_bat)))
+            for bt_ in bts:
+                bt_.synchronize()
+
+        spent, sizes = 0.0, []
+        for i in range(w_b + k_b):
+            trim(i * F)
+            t_b = time.perf_counter()
+            step_b(i)
+            if i >= w_b:
+                spent += time.perf_counter() - t_b
+                sizes.append(float(np.mean([h_.map_size() for h_ in hs])))
+        fps_b = B * F * k_b / spent
+        m_b = float(np.mean(sizes))
+        b_alg_b = 9 * n_pix + 60 * n_seed + 88 * m_b + 44 * (k_avg or 1400.0)
+        out["bounded_map"] = {"value": round(fps_b, 1), "unit": "frames/s", "mean_live_surfels": round(m_b), "steps": k_b,
+                              "e2e_algorithmic_GBps": round(fps_b * b_alg_b / 1e9, 2),
+                              "e2e_hbm_frac_bounded_map": round(fps_b * b_alg_b / 1e9 / HBM_PEAK_GBS, 5),
+                              "note": "same batched replay; between steps every handle moves the keyframes older than 10 to its "
+                                      "inactive store (dsm_store_deactivate, untimed), as the node's drift-free window does"}
+        for bt_ in bts:
+            bt_.close()
+        for h_ in hs:
+            h_.close()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cam, scenes[0], rendered[0], period, lo_t, hi_t)
         if k_avg is None:
@@ -668,8 +801,13 @@ def main():
     b_alg_frame = 9 * n_pix + 60 * n_seed + 88 * m_avg + 44 * k_avg
     out["e2e_algorithmic_GBps"] = round(fps * b_alg_frame / 1e9, 2)
     out["e2e_hbm_frac"] = round(fps * b_alg_frame / 1e9 / (HBM_PEAK_GBS * world), 5)
+    # what the end-to-end fraction is made of: 88 B per live surfel of a map this replay lets grow
+    # without bound (no keyframe ever leaves the window), and the superpixel stages' own 9N + 60S
+    out["e2e_hbm_frac_note"] = (f"growing map: mean {round(m_avg)} live surfels, {round(100 * 88 * m_avg / b_alg_frame)} % of B_alg is the 88 B/surfel "
+                                "map term; see bounded_map for the window the node keeps")
+    out["superpixel_stage_hbm_frac"] = round(fps * (9 * n_pix + 60 * n_seed) / 1e9 / (HBM_PEAK_GBS * world), 5)
     if args.mode == "batched":
-        out["valu_issue"] = valu_issue(fps / world)
+        out["valu_issue"] = valu_issue(fps / world, clock.ghz())
 
     if rank == 0:
         print(json.dumps(out))

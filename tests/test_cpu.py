@@ -810,3 +810,29 @@ def test_bench_gpus_flag_fails_loudly_without_devices():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "visible GPUs" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_eigen_last_place_exposure_is_bounded(oracle_built):
+    """The two Eigen operations of the hot path (Matrix4f::inverse FF.cpp:59, Matrix4d::inverse FF.cpp:176) are restated,
+    not pinned (Eigen is absent).  tools/eigen_exposure.py moves every element of either result by one ulp inside the
+    reference's own TU and replays a sequence; profiles/r03_eigen_exposure.md holds the table for 100 frames at 1226x370.
+    Gate, on a short sequence: the double inverse of the Gauss-Newton step has no effect at all (the update is rounded to
+    float), the float inverse of the pose changes no surfel count here and moves floats by < 1e-3 relative."""
+    if not os.path.isdir("/root/reference/surfel_fusion/src"):
+        pytest.skip("needs the reference sources (the perturbable TU is built from them)")
+    subprocess.run(["make", "-s", "-C", oracle_built, "perturb"], check=True)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eigen_exposure
+    jobs = [("TINY", 30, name, f, d) for name, f, d in eigen_exposure.patterns(n_random=2)]
+    res = [eigen_exposure.replay(j) for j in jobs[:1]]
+    keep = [j for j in jobs[1:] if "random" in j[2] or j[2].endswith("[0]+1ulp") or j[2].endswith("[14]-1ulp")]
+    res += [eigen_exposure.replay(j) for j in keep]
+    base = res[0]
+    for name, counts, m in res[1:]:
+        row = eigen_exposure.compare(base[1], base[2], counts, m)
+        if name.startswith("gn_inverse_f64"):
+            assert row["first_frame_with_other_counts"] is None and row["surfels_differing_in_any_bit"] == 0, (name, row)
+        else:
+            assert abs(row["final_surfels"] - row["final_surfels_baseline"]) <= 2, (name, row)
+            if row["first_frame_with_other_counts"] is None:
+                assert row["integer_fields_changed"] == 0 and row["max_rel_float_drift"] < 1e-3, (name, row)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r02_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass).
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass).
 
     python tools/pmc_traffic.py gpurun_out/pmc_<fetch-tag> gpurun_out/pmc_<write-tag> profiles/r02_pmc_traffic.json "<command>"
 
@@ -42,7 +42,11 @@ def single_name(k):
     if base == "k_seed_fit":  # <BATCH, tier>: the one-subsequence launch has a single tier
         return base
     args = [a.strip() for a in args.split(",")]
-    if args[-1] == "false":
+    if base == "k_assign":  # <FIRST, BATCH, pixels per thread>
+        args = args[:1]
+    elif base == "k_update_seeds_wave":  # the one-subsequence form of the update_seeds stage
+        base, args = "k_update_seeds", args[:1]
+    elif args[-1] == "false":
         args = args[:-1]
     return base + ("<" + ", ".join(args) + ">" if args else "")
 
@@ -55,7 +59,7 @@ def main():
     fetch = {name(k): v for k, v in per_kernel(fetch_dir, "FETCH_SIZE").items()}
     write = {name(k): v for k, v in per_kernel(write_dir, "WRITE_SIZE").items()}
     n = W * H
-    cal_name = "k_assign<true, true>" if nb > 1 else "k_assign<true>"
+    cal_name = "k_assign<true, true, 4>" if nb > 1 else "k_assign<true>"
     n *= nb
     cal_f = (5 * n / 1024.0) / fetch[cal_name]
     cal_w = (4 * n / 1024.0) / write[cal_name]
