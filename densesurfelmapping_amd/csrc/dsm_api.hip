@@ -27,6 +27,8 @@ namespace {
 thread_local std::string g_create_error;
 
 constexpr int kParamRing = 4096;
+constexpr int kMaxPipes = 32;
+constexpr uint64_t kSerialBit = 1ull << 63;
 constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 
 void batch_streams_reserve(int device); // see BatchStreamPool
@@ -130,14 +132,14 @@ struct dsm_handle {
         hipGraphExec_t g_sp = nullptr, g_map[2] = {nullptr, nullptr}, g_all[2] = {nullptr, nullptr};
         hipGraphExec_t g_sp_main = nullptr; // superpixel stages on the map stream (drop-in calls)
         hipEvent_t ev_sp = nullptr, ev_map = nullptr;
-    } pipe[16];
+    } pipe[kMaxPipes];
     int n_pipe = 1;
     // frame groups (pipeline_depth >= 4): the superpixel stages of n_pipe / 2 consecutive frames as ONE batched launch
     // per kernel over that half of the pipelines (submit_group)
     DeviceCtx *d_pipe_ctxs = nullptr;                 // [n_pipe] the pipelines' contexts, for the batched kernels
     hipGraphExec_t g_group[4] = {nullptr, nullptr, nullptr, nullptr}; // superpixel stages of pipelines [kG, (k+1)G)
     hipGraphExec_t g_group_map[4] = {nullptr, nullptr, nullptr, nullptr}; // their fuse + tail stages, frame after frame
-    unsigned params_pending = 0; // bit p: pipeline p has not yet waited for the latest params upload
+    uint64_t params_pending = 0; // bit p: pipeline p has not yet waited for the latest params upload; kSerialBit: the map stream (serial / drop-in calls)
     hipStream_t copy_stream = nullptr; // per-frame params go up here, so that they never queue behind the map stream
     hipEvent_t ev_params = nullptr;
     std::vector<void *> allocs; // every hipMalloc of this handle
@@ -236,7 +238,7 @@ int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16) {
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, &fp, sizeof fp, hipMemcpyHostToDevice, h->copy_stream));
     HIP_TRY(h, hipEventRecord(h->ev_params, h->copy_stream));
-    h->params_pending = ~0u;
+    h->params_pending = ~0ull;
     return DSM_OK;
 }
 
@@ -262,7 +264,7 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
     } else {
         HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(h, hipEventRecord(h->ev_params, h->copy_stream));
-        h->params_pending = ~0u;
+        h->params_pending = ~0ull;
     }
     *staged = m;
     return DSM_OK;
@@ -317,9 +319,9 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
         // the pipeline's buffers are free once the map stream has finished the frame that used them last,
         // and the frame's params must have landed
         HIP_TRY(h, hipStreamWaitEvent(pp.stream, pp.ev_map, 0));
-        if (h->params_pending & (1u << p)) {
+        if (h->params_pending & (1ull << p)) {
             HIP_TRY(h, hipStreamWaitEvent(pp.stream, h->ev_params, 0));
-            h->params_pending &= ~(1u << p);
+            h->params_pending &= ~(1ull << p);
         }
         if (eager) {
             hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, pp.stream, nullptr, 0, kLastSuperpixelStage);
@@ -376,7 +378,7 @@ int submit_group(dsm_handle *h) {
     // and the map stream waits for lead.ev_sp below.  A later submit_frame on one of these pipelines (ragged end of a
     // replay) stages its own params first, which sets its bit again (stage_params: params_pending = ~0u) -- so a cleared
     // bit never stands for an upload its stream has not been ordered behind.
-    const unsigned mask = ((1u << G) - 1u) << p0;
+    const uint64_t mask = ((1ull << G) - 1ull) << p0;
     if (h->params_pending & mask) {
         HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->ev_params, 0));
         h->params_pending &= ~mask;
@@ -425,9 +427,9 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
     h->shadow_n = -1;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
-    if (h->n_pipe > 1 && (h->params_pending & 0x80000000u)) {
+    if (h->n_pipe > 1 && (h->params_pending & kSerialBit)) {
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
-        h->params_pending &= ~0x80000000u;
+        h->params_pending &= ~kSerialBit;
     }
     hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, ev, lo, hi);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -449,9 +451,9 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
 int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
-    if (h->n_pipe > 1 && (h->params_pending & 0x80000000u)) {
+    if (h->n_pipe > 1 && (h->params_pending & kSerialBit)) {
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
-        h->params_pending &= ~0x80000000u;
+        h->params_pending &= ~kSerialBit;
     }
     const int lo = map_part ? kLastSuperpixelStage + 1 : 0, hi = map_part ? kNumStages - 1 : kLastSuperpixelStage;
     if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
@@ -763,7 +765,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &h->d_stage_depth, (size_t)w * hh));
     // per-pipeline superpixel state
     int np = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
-    if (np != 1 && np != 2 && np != 4 && np != 8 && np != 16) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4, 8 or 16"); return bail(DSM_E_INVALID); }
+    if (np != 1 && np != 2 && np != 4 && np != 8 && np != 16 && np != 32) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4, 8, 16 or 32"); return bail(DSM_E_INVALID); }
     h->n_pipe = np;
     if (np > 1) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
@@ -811,7 +813,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     h->hc = h->pipe[0].ctx;
     if (np >= 4) {
         CREATE_TRY(dev_alloc(h, &h->d_pipe_ctxs, (size_t)np));
-        DeviceCtx tmp[16];
+        DeviceCtx tmp[kMaxPipes];
         for (int p = 0; p < np; p++) tmp[p] = h->pipe[p].ctx;
         CREATE_TRY(hipMemcpyAsync(h->d_pipe_ctxs, tmp, sizeof(DeviceCtx) * (size_t)np, hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipStreamSynchronize(h->stream)); // tmp is on the stack
@@ -836,7 +838,7 @@ void dsm_destroy(dsm_handle *h) {
         if (h->g_group[i]) (void)hipGraphExecDestroy(h->g_group[i]);
         if (h->g_group_map[i]) (void)hipGraphExecDestroy(h->g_group_map[i]);
     }
-    for (int p = 0; p < 16; p++) {
+    for (int p = 0; p < kMaxPipes; p++) {
         dsm_handle::Pipe &pp = h->pipe[p];
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
         if (pp.g_sp) (void)hipGraphExecDestroy(pp.g_sp);
@@ -1381,7 +1383,7 @@ int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap) {
     for (int p = 0; p < h->n_pipe; p++) h->pipe[p].ctx.fit_small_cap = cap;
     h->hc.fit_small_cap = cap;
     if (h->d_pipe_ctxs) {
-        DeviceCtx tmp[16];
+        DeviceCtx tmp[kMaxPipes];
         for (int p = 0; p < h->n_pipe; p++) tmp[p] = h->pipe[p].ctx;
         HIP_TRY(h, hipMemcpy(h->d_pipe_ctxs, tmp, sizeof(DeviceCtx) * (size_t)h->n_pipe, hipMemcpyHostToDevice));
     }

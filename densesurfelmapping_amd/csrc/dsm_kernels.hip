@@ -1950,22 +1950,39 @@ __device__ __forceinline__ int tail_spawn_list(const DeviceCtx *__restrict__ c, 
 
 // ------------------------------------------------------------------------------ hole scan
 // Ascending list of deleted slots (SM.cpp:1078-1083) from the per-wave bitmaps.
+// A thread owns kScanWords consecutive bitmap words per round (two 16-byte loads each pair, coalesced across the block): one
+// block scan orders 8 192 words = 524 288 surfels, so a 2 M-surfel map takes four rounds and an 8 M one sixteen (one word
+// per thread and round: 31 and 122).
+constexpr int kScanWords = 8;
 __device__ __forceinline__ int tail_hole_scan(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */, int M) {
     const int n_word = (M + 63) >> 6;
     int run = 0;
-    for (int base = 0; base < n_word; base += 1024) {
-        const int v = base + threadIdx.x;
-        unsigned long long m = 0;
-        if (v < n_word) m = c->hole_mask[v];
+    for (int base = 0; base < n_word; base += 1024 * kScanWords) {
+        const int v0 = base + (int)threadIdx.x * kScanWords;
+        unsigned long long m[kScanWords];
+#pragma unroll
+        for (int q = 0; q < kScanWords; q += 2) { // (the allocation holds cap / 64 + 1 words, rounded up by dev_alloc's slack)
+            ulonglong2 two = make_ulonglong2(0, 0);
+            if (v0 + q < n_word) two = *reinterpret_cast<const ulonglong2 *>(c->hole_mask + v0 + q);
+            m[q] = two.x;
+            m[q + 1] = v0 + q + 1 < n_word ? two.y : 0ull;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < kScanWords; q++) cnt += __popcll(m[q]);
         int excl;
-        const int total = block_scan_1024(__popcll(m), excl, s_wave);
-        if (v < n_word) {
-            int o = run + excl;
-            c->wave_prefix[v] = o;
-            while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                c->holes[o++] = v * 64 + b;
-                m &= m - 1;
+        const int total = block_scan_1024(cnt, excl, s_wave);
+        int o = run + excl;
+#pragma unroll
+        for (int q = 0; q < kScanWords; q++) {
+            if (v0 + q < n_word) {
+                c->wave_prefix[v0 + q] = o;
+                unsigned long long w = m[q];
+                while (w) {
+                    const int b = __ffsll((long long)w) - 1;
+                    c->holes[o++] = (v0 + q) * 64 + b;
+                    w &= w - 1;
+                }
             }
         }
         run += total;

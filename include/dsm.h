@@ -86,7 +86,7 @@ typedef struct dsm_config {
     int32_t frame_slots;      /* resident frame slots in HBM; 0 = default (2) */
     uint32_t flags;           /* DSM_FLAG_* */
     int32_t pipeline_depth;   /* frames of one sequence whose superpixel stages may be in flight at once
-                                 (1, 2, 4, 8 or 16); 0 = default (4).  Results do not depend on it.  From 4 on,
+                                 (1, 2, 4, 8, 16 or 32); 0 = default (4).  Results do not depend on it.  From 4 on,
                                  dsm_replay_enqueue launches the superpixel stages of depth / 2 consecutive frames as one
                                  batch (every kernel once for all of them) while fuse + compaction of the previous
                                  group run in frame order. */
