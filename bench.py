@@ -576,7 +576,7 @@ def main():
         # only fuse + tail need the map -- the superpixel stages of up to 8 frames run ahead on their own streams
         s1, r1, p1 = plans[0]
         by_depth = {}
-        for depth in (16, 32):
+        for depth in (16, 24, 32):
             ff = make_handle(0, pipeline_depth=depth)
             ff.replay_enqueue(s1[:lo_t], r1[:lo_t], p1[:lo_t])
             ff.synchronize()
@@ -591,7 +591,7 @@ def main():
                                   "host_enqueue_seconds": by_depth[best][1],
                                   "frames_per_s_by_pipeline_depth": {str(d_): v[0] for d_, v in by_depth.items()},
                                   "note": "one subsequence, one handle: the superpixel stages of depth/4 consecutive frames as one batched "
-                                          "launch per kernel (four groups of pipelines in turn), fuse + compaction strictly in "
+                                          "launch per kernel (three or four groups of pipelines in turn; three leave the map stream a hardware queue of its own), fuse + compaction strictly in "
                                           "frame order on the map stream; same results as the serial order"}
     if extras:
         # the synchronous drop-in call (host buffers in and out over PCIe every frame), for DESIGN.md;

@@ -31,7 +31,9 @@ constexpr int kMaxPipes = 32;
 constexpr uint64_t kSerialBit = 1ull << 63;
 constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 
+constexpr int kBatchStreams = 4;
 void batch_streams_reserve(int device); // see BatchStreamPool
+hipStream_t batch_stream_at(int device, int i);
 
 } // namespace
 
@@ -122,16 +124,19 @@ struct dsm_handle {
     dsm_config cfg;
     int device = 0;
     hipStream_t stream = nullptr; // the map stream: fuse + tail of every frame, in frame order; uploads; params
+    bool own_stream = true;
     DeviceCtx hc;              // context of the pipeline that handled the latest frame (taps, shared pointers)
     // Superpixel stages (init_seeds .. seed_planes) depend on the frame only, so frame f runs them on pipeline
     // f % n_pipe -- its own stream and its own superpixel buffers -- while the map stream still fuses
     // earlier frames.  fuse_surfels + frame_tail of frame f wait for them and run in frame order.
     struct Pipe {
         hipStream_t stream = nullptr;
+        bool own_stream = true; // false: one of the device's reserved per-queue streams (frame-group leads)
         DeviceCtx ctx;
         hipGraphExec_t g_sp = nullptr, g_map[2] = {nullptr, nullptr}, g_all[2] = {nullptr, nullptr};
         hipGraphExec_t g_sp_main = nullptr; // superpixel stages on the map stream (drop-in calls)
         hipEvent_t ev_sp = nullptr, ev_map = nullptr;
+        hipEvent_t ev_free = nullptr; // what says this pipeline's buffers are free again: its own ev_map, or the one recorded for its whole frame group
     } pipe[kMaxPipes];
     int n_pipe = 1;
     // frame groups (pipeline_depth >= 4): the superpixel stages of n_pipe / 2 consecutive frames as ONE batched launch
@@ -318,7 +323,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
     } else {
         // the pipeline's buffers are free once the map stream has finished the frame that used them last,
         // and the frame's params must have landed
-        HIP_TRY(h, hipStreamWaitEvent(pp.stream, pp.ev_map, 0));
+        HIP_TRY(h, hipStreamWaitEvent(pp.stream, pp.ev_free ? pp.ev_free : pp.ev_map, 0));
         if (h->params_pending & (1ull << p)) {
             HIP_TRY(h, hipStreamWaitEvent(pp.stream, h->ev_params, 0));
             h->params_pending &= ~(1ull << p);
@@ -342,7 +347,10 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
             HIP_TRY(h, hipGraphLaunch(pp.g_map[wc], h->stream));
         }
     }
-    if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+    if (h->n_pipe > 1) {
+        HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+        pp.ev_free = pp.ev_map;
+    }
     h->hc = pp.ctx; // taps read the state of the latest frame
     h->frames_submitted++;
     if (with_compaction) {
@@ -358,7 +366,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
 // then follow on the map stream in frame order.  The pipelines form two groups (four from depth 16 on) used in turn,
 // so the batches of the next group(s) run while the map stream works the previous one off.  Same results as frame by
 // frame; the params of the G frames must have been staged, and frames_submitted be a multiple of G.
-int group_size(const dsm_handle *h) { return h->n_pipe >= 16 ? h->n_pipe / 4 : h->n_pipe / 2; }
+int group_size(const dsm_handle *h) { return (h->n_pipe == 12 || h->n_pipe == 24) ? h->n_pipe / 3 : h->n_pipe >= 16 ? h->n_pipe / 4 : h->n_pipe / 2; }
 bool group_path(const dsm_handle *h) {
     return h->n_pipe >= 4 && h->d_pipe_ctxs && !(h->cfg.flags & DSM_FLAG_NO_GRAPH);
 }
@@ -372,7 +380,10 @@ int submit_group(dsm_handle *h) {
     dsm_handle::Pipe &lead = h->pipe[half];
     // the group's buffers are free once the map stream has finished the frames that used them last (it is in order:
     // the last pipeline's event covers the others), and the frames' params must have landed
-    HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->pipe[p0 + G - 1].ev_map, 0));
+    {
+        const dsm_handle::Pipe &last = h->pipe[p0 + G - 1];
+        HIP_TRY(h, hipStreamWaitEvent(lead.stream, last.ev_free ? last.ev_free : last.ev_map, 0));
+    }
     // Only the lead stream waits for the params upload, yet the bits of all G pipelines are cleared: the group's
     // superpixel launch on `lead` is the only work that reads the params of these G frames before the map stream does,
     // and the map stream waits for lead.ev_sp below.  A later submit_frame on one of these pipelines (ragged end of a
@@ -414,7 +425,9 @@ int submit_group(dsm_handle *h) {
         if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
     }
     HIP_TRY(h, hipGraphLaunch(h->g_group_map[half], h->stream));
-    for (int j = 0; j < G; j++) HIP_TRY(h, hipEventRecord(h->pipe[p0 + j].ev_map, h->stream));
+    // ONE event for the group (every record is a marker packet on the map stream, the serial spine of a sequence)
+    HIP_TRY(h, hipEventRecord(h->pipe[p0 + G - 1].ev_map, h->stream));
+    for (int j = 0; j < G; j++) h->pipe[p0 + j].ev_free = h->pipe[p0 + G - 1].ev_map;
     h->hc = h->pipe[p0 + G - 1].ctx; // taps read the state of the latest frame
     h->frames_submitted += G;
     const int64_t up = (int64_t)h->map_upper + (int64_t)G * h->hc.n_seed;
@@ -433,7 +446,10 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
     }
     hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, ev, lo, hi);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
-    if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+    if (h->n_pipe > 1) {
+        HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+        pp.ev_free = pp.ev_map;
+    }
     h->hc = pp.ctx;
     h->fence_pending = true; // (timed / debug replays: uploads wait for the whole stream)
     if (hi == kNumStages - 1) { // the tail advanced the pipeline's cursor
@@ -466,7 +482,10 @@ int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
         HIP_TRY(h, hipGraphLaunch(*g, h->stream));
     }
     if (map_part) {
-        if (h->n_pipe > 1) HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+        if (h->n_pipe > 1) {
+            HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
+            pp.ev_free = pp.ev_map;
+        }
         h->hc = pp.ctx;
         h->frames_submitted++;
         if (with_compaction) {
@@ -708,7 +727,13 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
     batch_streams_reserve(h->device); // (before any handle stream of this process: see BatchStreamPool)
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // Depths 12 and 24 run THREE frame groups: their lead streams and the map stream are the device's four reserved
+    // streams, one hardware queue each.  (With four groups the map stream shares a queue with one of them, and a stream
+    // waiting for an event holds up whatever else is queued behind it on the same hardware queue.)
+    const int np_req = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
+    if (np_req == 12 || np_req == 24) h->stream = batch_stream_at(h->device, kBatchStreams - 1);
+    if (h->stream) h->own_stream = false;
+    else CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->up_stream = h->stream;
     if (cfg->flags & DSM_FLAG_UPLOAD_STREAM) {
         CREATE_TRY(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
@@ -765,7 +790,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &h->d_stage_depth, (size_t)w * hh));
     // per-pipeline superpixel state
     int np = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
-    if (np != 1 && np != 2 && np != 4 && np != 8 && np != 16 && np != 32) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4, 8, 16 or 32"); return bail(DSM_E_INVALID); }
+    if (np != 1 && np != 2 && np != 4 && np != 8 && np != 12 && np != 16 && np != 24 && np != 32) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4, 8, 12, 16, 24 or 32"); return bail(DSM_E_INVALID); }
     h->n_pipe = np;
     if (np > 1) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
@@ -777,7 +802,11 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         DeviceCtx &q = pp.ctx;
         q.cursor_mul = np; q.cursor_add = p;
         if (np > 1) {
-            CREATE_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
+            // frame groups launch on the streams of pipelines 0..3 (submit_group): those are the device's four reserved
+            // streams, one per hardware queue (BatchStreamPool), so that the groups' batches never share a queue
+            if (np >= 4 && p < kBatchStreams - ((np == 12 || np == 24) ? 1 : 0)) pp.stream = batch_stream_at(h->device, p);
+            if (pp.stream) pp.own_stream = false;
+            else CREATE_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
             CREATE_TRY(hipEventCreateWithFlags(&pp.ev_sp, hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&pp.ev_map, hipEventDisableTiming));
         }
@@ -849,7 +878,7 @@ void dsm_destroy(dsm_handle *h) {
         }
         if (pp.ev_sp) (void)hipEventDestroy(pp.ev_sp);
         if (pp.ev_map) (void)hipEventDestroy(pp.ev_map);
-        if (pp.stream) (void)hipStreamDestroy(pp.stream);
+        if (pp.stream && pp.own_stream) (void)hipStreamDestroy(pp.stream);
     }
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->own_up_stream && h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
@@ -868,7 +897,7 @@ void dsm_destroy(dsm_handle *h) {
     if (h->pin_frame) (void)hipHostFree(h->pin_frame);
     if (h->pin_map) (void)hipHostFree(h->pin_map);
     delete h->pool;
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -1411,7 +1440,6 @@ int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
 // busy 45 % and 54 % of the time, the other two 78 % and 73 %).  The first four streams of a process, created together
 // before anything else, get a queue each; batches take them in turn.  Created by the first dsm_create on the device.
 namespace {
-constexpr int kBatchStreams = 4;
 struct BatchStreamPool {
     std::mutex mu;
     hipStream_t st[64][kBatchStreams] = {};
@@ -1426,6 +1454,11 @@ void batch_streams_reserve(int device) {
     g_batch_streams.made[device] = true;
     for (int i = 0; i < kBatchStreams; i++)
         if (hipStreamCreateWithFlags(&g_batch_streams.st[device][i], hipStreamNonBlocking) != hipSuccess) g_batch_streams.st[device][i] = nullptr;
+}
+hipStream_t batch_stream_at(int device, int i) {
+    if (device < 0 || device >= 64 || i < 0 || i >= kBatchStreams) return nullptr;
+    std::lock_guard<std::mutex> lk(g_batch_streams.mu);
+    return g_batch_streams.made[device] ? g_batch_streams.st[device][i] : nullptr;
 }
 hipStream_t batch_stream_take(int device) {
     if (device < 0 || device >= 64) return nullptr;

@@ -71,7 +71,7 @@ def test_long_sequence_kitti_golden(mods, gold):
 
     # default pipeline depth (4: the superpixel stages of two consecutive frames per batched launch), then 16 and 32 (four
     # and eight per launch; the 50-frame chunks leave ragged ends that go frame by frame)
-    for depth in (0, 16, 32):  # 32: eight frames per batched launch -- the lane-per-seed forms of the per-seed stages
+    for depth in (0, 16, 24, 32):  # 24, 32: eight frames per batched launch -- the lane-per-seed forms of the per-seed stages (24: three groups)
         ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20, pipeline_depth=depth)
         for t in range(period):
             ff.frame_upload(t, frames[t][1], frames[t][2])
