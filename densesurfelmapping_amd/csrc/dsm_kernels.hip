@@ -1741,11 +1741,12 @@ __device__ __forceinline__ void records_to_lds(float *s_rec, const dsm_surfel *s
             for (int e = v * 4; e < n_dw; e++) s_rec[e] = s1[e];
     }
 }
+__device__ __forceinline__ void rec_store(float4 *p, const float4 &v);
 __device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s_rec, int cnt, int tid) {
     const int n_dw = cnt * kRecDw;
     float *d1 = reinterpret_cast<float *>(dst);
     for (int v = tid; v * 4 < n_dw; v += 256) {
-        if (v * 4 + 4 <= n_dw) reinterpret_cast<float4 *>(d1)[v] = reinterpret_cast<const float4 *>(s_rec)[v];
+        if (v * 4 + 4 <= n_dw) rec_store(reinterpret_cast<float4 *>(d1) + v, reinterpret_cast<const float4 *>(s_rec)[v]);
         else
             for (int e = v * 4; e < n_dw; e++) d1[e] = s_rec[e];
     }
@@ -1759,14 +1760,26 @@ __device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s
 struct RecRegs {
     float4 v0, v1, v2; // 256 records = 704 16-byte vectors: 2.75 per thread
 };
+// The map-sized kernels stream every record once per launch: non-temporal loads and stores (no reuse worth a cache line:
+// k_warp at 8 M surfels 170 -> 157 us, 4.15 -> 4.5 TB/s; the headline, whose maps are re-read one frame later from
+// whatever cache still holds them, is unchanged).  The builtins want a native vector type, not HIP's float4 struct.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rec_load(const float4 *p) {
+    const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void rec_store(float4 *p, const float4 &v) {
+    v4f_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
+}
 __device__ __forceinline__ RecRegs records_issue(const dsm_surfel *src, int cnt, int tid) {
     const int n_dw = cnt * kRecDw;
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     // unconditional (a vector beyond the block re-reads vector 0): no branch to wait behind
     RecRegs p;
-    p.v0 = s4[tid * 4 + 4 <= n_dw ? tid : 0];
-    p.v1 = s4[(tid + 256) * 4 + 4 <= n_dw ? tid + 256 : 0];
-    p.v2 = s4[(tid + 512) * 4 + 4 <= n_dw ? tid + 512 : 0];
+    p.v0 = rec_load(s4 + (tid * 4 + 4 <= n_dw ? tid : 0));
+    p.v1 = rec_load(s4 + ((tid + 256) * 4 + 4 <= n_dw ? tid + 256 : 0));
+    p.v2 = rec_load(s4 + ((tid + 512) * 4 + 4 <= n_dw ? tid + 512 : 0));
     return p;
 }
 __device__ __forceinline__ void records_land_one(float *s_rec, const float4 &val, const float *s1, int n_dw, int v) {
@@ -2273,7 +2286,7 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
         }
         __syncthreads();
         for (int v = tid; v < n_vec; v += 256) {
-            if (whole || v < n_vec - 1) dst[v] = lds4[v];
+            if (whole || v < n_vec - 1) rec_store(dst + v, lds4[v]);
             else {
                 float *d1 = reinterpret_cast<float *>(surfels + base);
                 for (int e = v * 4; e < cnt * 11; e++) d1[e] = s_rec[e];
