@@ -35,6 +35,7 @@ struct Emu {
     const float *dep; size_t dep_step;
     int order_salt = 0; // permutes "thread" execution order to exercise order independence
     std::set<long long> unsure_waves; long long sweep_id = 0;
+    long long gn_seeds = 0, gn_seeds_mask_changed = 0, gn_steps = 0, gn_steps_mask_changed = 0; // Gauss-Newton steps 2..5 whose Huber classes differ from the step before
     long long fast_total = 0, fast_unsure = 0, fast_mismatches = 0, fast_checked = 0, fast_bound_violations = 0; // pick_seed_fast
 
     float I(int x, int y) const { return (float)img[(size_t)y * img_step + x]; }
@@ -228,14 +229,22 @@ void seed_planes(Emu &e) {
                 nx = nx / len; ny = ny / len; nz = nz / len;
                 mx /= (float)m; my /= (float)m; mz /= (float)m;
                 for (int i = 0; i < m; i++) { lp[i * 3] -= mx; lp[i * 3 + 1] -= my; lp[i * 3 + 2] -= mz; }
+                char prev_core[256] = {0};
+                bool changed_any = false;
+                e.gn_seeds++;
                 for (int it = 0; it < 5; it++) {
                     double acc[20];
                     float res[256];
                     int cls[256];
+                    bool same = it > 0;
                     for (int i = 0; i < m; i++) {
                         res[i] = lp[i * 3] * nx + lp[i * 3 + 1] * ny + lp[i * 3 + 2] * nz + nb;
-                        cls[i] = huber_class32(res[i], flt_above(e.huber));
+                        const int cl = huber_class32(res[i], flt_above(e.huber));
+                        same = same && ((cl == 0) == (prev_core[i] != 0));
+                        cls[i] = cl;
+                        prev_core[i] = cl == 0;
                     }
+                    if (it > 0) { e.gn_steps++; if (!same) e.gn_steps_mask_changed++; if (!same) changed_any = true; }
                     for (int lane = 0; lane < 20; lane++) {
                         const bool is_j = lane >= 16;
                         const int ta = lane < 16 ? (lane & 3) : ((lane - 16) & 3), tb = (lane >> 2) & 3;
@@ -249,6 +258,7 @@ void seed_planes(Emu &e) {
                     }
                     gn_step(acc, acc + 16, nx, ny, nz, nb);
                 }
+                if (changed_any) e.gn_seeds_mask_changed++;
                 plane_finish(nx, ny, nz, nb, mx, my, mz);
                 const SeedGeom g = seed_geometry(e.K, core.x, core.y, md, nx, ny, nz, nb);
                 out.norm_x = g.nx; out.norm_y = g.ny; out.norm_z = g.nz;
@@ -346,11 +356,13 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 }
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
-// pick_seed_fast over every pixel assigned so far: out[8] = [pixels, unsure, answered differently from pick_seed, costs checked,
+// pick_seed_fast over every pixel assigned so far: out[12] (8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
+// out[0..7] = [pixels, unsure, answered differently from pick_seed, costs checked,
 // bound violated, 64-pixel row segments (waves) with an unsure pixel, sweeps]
 void emu_fast_pick_stats(void *p, long long *out) {
     Emu &e = *(Emu *)p;
     out[5] = (long long)e.unsure_waves.size(); out[6] = e.sweep_id;
+    out[8] = e.gn_seeds; out[9] = e.gn_seeds_mask_changed; out[10] = e.gn_steps; out[11] = e.gn_steps_mask_changed;
     out[0] = e.fast_total; out[1] = e.fast_unsure; out[2] = e.fast_mismatches; out[3] = e.fast_checked; out[4] = e.fast_bound_violations;
 }
 

@@ -159,7 +159,7 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
         assert not fields_equal(le, lo), t
     # the filtered pick of k_assign (dsm_math.h, pick_seed_fast), run beside the reference's on every pixel of every sweep:
     # it never answers differently, its error bound holds on every candidate cost, and it answers nearly always
-    st = (C.c_longlong * 8)()
+    st = (C.c_longlong * 12)()
     emu.lib.emu_fast_pick_stats.argtypes = [C.c_void_p, C.c_void_p]
     emu.lib.emu_fast_pick_stats(emu.h, st)
     pixels, unsure, mismatches, checked, violations = list(st)[:5]
