@@ -35,6 +35,7 @@ struct Emu {
     const float *dep; size_t dep_step;
     int order_salt = 0; // permutes "thread" execution order to exercise order independence
     std::set<long long> unsure_waves; long long sweep_id = 0;
+    long long gn_first_noncore = 0; // seeds with a residual outside the Huber core at step 1
     long long gn_seeds = 0, gn_seeds_mask_changed = 0, gn_steps = 0, gn_steps_mask_changed = 0; // Gauss-Newton steps 2..5 whose Huber classes differ from the step before
     long long fast_total = 0, fast_unsure = 0, fast_mismatches = 0, fast_checked = 0, fast_bound_violations = 0; // pick_seed_fast
 
@@ -244,6 +245,7 @@ void seed_planes(Emu &e) {
                         cls[i] = cl;
                         prev_core[i] = cl == 0;
                     }
+                    if (it == 0) { bool any = false; for (int i = 0; i < m; i++) any = any || cls[i] != 0; if (any) e.gn_first_noncore++; }
                     if (it > 0) { e.gn_steps++; if (!same) e.gn_steps_mask_changed++; if (!same) changed_any = true; }
                     for (int lane = 0; lane < 20; lane++) {
                         const bool is_j = lane >= 16;
@@ -356,12 +358,13 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 }
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
-// pick_seed_fast over every pixel assigned so far: out[12] (8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
+// pick_seed_fast over every pixel assigned so far: out[12] (7: seeds with a non-core residual at step 1; 8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
 // out[0..7] = [pixels, unsure, answered differently from pick_seed, costs checked,
 // bound violated, 64-pixel row segments (waves) with an unsure pixel, sweeps]
 void emu_fast_pick_stats(void *p, long long *out) {
     Emu &e = *(Emu *)p;
     out[5] = (long long)e.unsure_waves.size(); out[6] = e.sweep_id;
+    out[7] = e.gn_first_noncore;
     out[8] = e.gn_seeds; out[9] = e.gn_seeds_mask_changed; out[10] = e.gn_steps; out[11] = e.gn_steps_mask_changed;
     out[0] = e.fast_total; out[1] = e.fast_unsure; out[2] = e.fast_mismatches; out[3] = e.fast_checked; out[4] = e.fast_bound_violations;
 }

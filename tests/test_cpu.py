@@ -166,6 +166,7 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
     assert pixels >= frames * 3 * cam.width * cam.height * 0.9 and checked > pixels
     assert mismatches == 0 and violations == 0, (mismatches, violations)
     assert unsure < 0.02 * pixels, (unsure, pixels)
+    print(f"plane fit: {st[7]} of {st[8]} seeds with a residual outside the Huber core at step 1, {st[9]} with a class change later")
     print(f"pick_seed_fast: {unsure} of {pixels} pixels unsure ({100.0 * unsure / pixels:.3f} %), {checked} costs within their bound")
 
 
