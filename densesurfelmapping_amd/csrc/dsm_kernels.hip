@@ -1724,11 +1724,13 @@ template <bool BATCH, int TIER> __global__ __launch_bounds__(64) void k_seed_fit
 // ------------------------------------------------------------------------------ fuse surfels
 // One lane per surfel.  Pure gather: a surfel reads one depth pixel, one label and one seed and rewrites
 // only itself; the single shared write is the idempotent `fused` flag of the seed.
-// The 44-byte records are an array of structures: a block moves 256 of them (704 16-byte vectors) through LDS
-// with fully coalesced loads, a lane owns one record at a stride of 11 dwords (odd: conflict-free), and the
-// block is stored back -- again coalesced -- only if one of its surfels changed.  This is the stage that scales
-// with the map: 88 B per live surfel, HBM-bound for large maps.  Deleted slots are reported as one ballot per
-// wave (hole bitmap for the compaction).
+// The 44-byte records are an array of structures: a wave moves 64 of them (176 16-byte vectors) through its part of
+// the LDS tile with fully coalesced loads, a lane owns one record at a stride of 11 dwords (odd: conflict-free), and
+// the 64 are stored back -- again coalesced -- only if one of them changed.  This is the stage that scales
+// with the map: 88 B per live surfel.  For a map whose surfels are all in view (bench.py's fuse_8M) the time is one
+// quarter streaming the records in (55 us of 222 at 8 M surfels: 6.4 TB/s), one fifth the store-back, and the rest
+// the gathers: a wave's 64 surfels touch ~65 cache lines of label / depth / seed data, more bytes than its records.
+// Deleted slots are reported as one ballot per wave (hole bitmap for the compaction).
 constexpr int kRecDw = sizeof(dsm_surfel) / 4; // 11
 
 // coalesced copy of `cnt` consecutive records between global memory and LDS (records start 16-byte aligned)
@@ -1742,10 +1744,10 @@ __device__ __forceinline__ void records_to_lds(float *s_rec, const dsm_surfel *s
     }
 }
 __device__ __forceinline__ void rec_store(float4 *p, const float4 &v);
-__device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s_rec, int cnt, int tid) {
+template <int NT = 256> __device__ __forceinline__ void records_from_lds(dsm_surfel *dst, const float *s_rec, int cnt, int tid) {
     const int n_dw = cnt * kRecDw;
     float *d1 = reinterpret_cast<float *>(dst);
-    for (int v = tid; v * 4 < n_dw; v += 256) {
+    for (int v = tid; v * 4 < n_dw; v += NT) {
         if (v * 4 + 4 <= n_dw) rec_store(reinterpret_cast<float4 *>(d1) + v, reinterpret_cast<const float4 *>(s_rec)[v]);
         else
             for (int e = v * 4; e < n_dw; e++) d1[e] = s_rec[e];
@@ -1772,14 +1774,15 @@ __device__ __forceinline__ void rec_store(float4 *p, const float4 &v) {
     v4f_t t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
 }
-__device__ __forceinline__ RecRegs records_issue(const dsm_surfel *src, int cnt, int tid) {
+// (NT threads share the copy: a workgroup's 256 with 256 records, or a wave's 64 with 64 records -- 2.75 vectors per thread either way)
+template <int NT = 256> __device__ __forceinline__ RecRegs records_issue(const dsm_surfel *src, int cnt, int tid) {
     const int n_dw = cnt * kRecDw;
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     // unconditional (a vector beyond the block re-reads vector 0): no branch to wait behind
     RecRegs p;
     p.v0 = rec_load(s4 + (tid * 4 + 4 <= n_dw ? tid : 0));
-    p.v1 = rec_load(s4 + ((tid + 256) * 4 + 4 <= n_dw ? tid + 256 : 0));
-    p.v2 = rec_load(s4 + ((tid + 512) * 4 + 4 <= n_dw ? tid + 512 : 0));
+    p.v1 = rec_load(s4 + ((tid + NT) * 4 + 4 <= n_dw ? tid + NT : 0));
+    p.v2 = rec_load(s4 + ((tid + 2 * NT) * 4 + 4 <= n_dw ? tid + 2 * NT : 0));
     return p;
 }
 __device__ __forceinline__ void records_land_one(float *s_rec, const float4 &val, const float *s1, int n_dw, int v) {
@@ -1787,12 +1790,12 @@ __device__ __forceinline__ void records_land_one(float *s_rec, const float4 &val
     else if (v * 4 < n_dw) // ragged last vector of the array
         for (int e = v * 4; e < n_dw; e++) s_rec[e] = s1[e];
 }
-__device__ __forceinline__ void records_land(float *s_rec, const RecRegs &p, const dsm_surfel *src, int cnt, int tid) {
+template <int NT = 256> __device__ __forceinline__ void records_land(float *s_rec, const RecRegs &p, const dsm_surfel *src, int cnt, int tid) {
     const int n_dw = cnt * kRecDw;
     const float *s1 = reinterpret_cast<const float *>(src);
     records_land_one(s_rec, p.v0, s1, n_dw, tid);
-    records_land_one(s_rec, p.v1, s1, n_dw, tid + 256);
-    records_land_one(s_rec, p.v2, s1, n_dw, tid + 512);
+    records_land_one(s_rec, p.v1, s1, n_dw, tid + NT);
+    records_land_one(s_rec, p.v2, s1, n_dw, tid + 2 * NT);
 }
 
 template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
@@ -1820,17 +1823,22 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
         inv[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fp.inv[q])));
         pose[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fp.pose[q])));
     }
+    // A WAVE moves its own 64 records (2 816 B = 176 vectors, 16-byte aligned) through its own quarter of the LDS tile and
+    // never waits for the other three: no workgroup barrier, the waves of a CU drift apart and their loads, gathers and
+    // stores overlap instead of marching in step.
     const int stride = gridDim.x * 256;
+    float *s_w = s_rec + wv * 64 * kRecDw;
+    const int first = blk.x * 256 + wv * 64;
     RecRegs ahead = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-    if ((int)blk.x * 256 < M) ahead = records_issue(c->local + blk.x * 256, M - blk.x * 256 < 256 ? M - blk.x * 256 : 256, tid);
-    for (int base = blk.x * 256; base < M; base += stride) {
-        const int cnt = M - base < 256 ? M - base : 256;
-        records_land(s_rec, ahead, c->local + base, cnt, tid);
-        __syncthreads();
-        if (base + stride < M) ahead = records_issue(c->local + base + stride, M - base - stride < 256 ? M - base - stride : 256, tid);
+    if (first < M) ahead = records_issue<64>(c->local + first, M - first < 64 ? M - first : 64, lane);
+    for (int base = first; base < M; base += stride) {
+        const int cnt = M - base < 64 ? M - base : 64;
+        records_land<64>(s_w, ahead, c->local + base, cnt, lane);
+        wave_lds_sync();
+        if (base + stride < M) ahead = records_issue<64>(c->local + base + stride, M - base - stride < 64 ? M - base - stride : 64, lane);
         bool hole = false, changed = false;
-        if (tid < cnt) {
-            float *r = s_rec + tid * kRecDw;
+        if (lane < cnt) {
+            float *r = s_w + lane * kRecDw;
             Surfel e;
             e.px = r[0]; e.py = r[1]; e.pz = r[2]; e.nx = r[3]; e.ny = r[4]; e.nz = r[5];
             e.size = r[6]; e.color = r[7]; e.weight = r[8];
@@ -1873,9 +1881,10 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
             hole = e.update_times == 0;
         }
         const unsigned long long m = __ballot(hole);
-        if (lane == 0 && base + wv * 64 < M) c->hole_mask[(base >> 6) + wv] = m;
-        if (__syncthreads_or(changed ? 1 : 0)) records_from_lds(c->local + base, s_rec, cnt, tid);
-        __syncthreads();
+        if (lane == 0) c->hole_mask[base >> 6] = m;
+        wave_lds_sync();
+        if (__ballot(changed) != 0) records_from_lds<64>(c->local + base, s_w, cnt, lane); // (stored back only if a surfel of the 64 changed)
+        wave_lds_sync();
     }
 }
 
@@ -2230,69 +2239,55 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
                                               const uint8_t *__restrict__ group_on, float4 *__restrict__ cloud) {
     __shared__ __attribute__((aligned(16))) float s_rec[256 * 11];
     const int n = n_ptr ? n_ptr[0] : n_fixed;
-    const int tid = threadIdx.x;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    // a wave moves its own 64 records through its quarter of the tile (see k_fuse_surfels: no workgroup barrier)
+    float *s_w = s_rec + wv * 64 * 11;
     // without untouched groups to skip, every block is read: its records are fetched one trip ahead (records_issue)
     const bool stream_all = group_on == nullptr;
     const int stride = gridDim.x * 256;
+    const int first = blockIdx.x * 256 + wv * 64;
     RecRegs ahead = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-    if (stream_all && (int)blockIdx.x * 256 < n)
-        ahead = records_issue(surfels + blockIdx.x * 256, n - (int)blockIdx.x * 256 < 256 ? n - (int)blockIdx.x * 256 : 256, tid);
-    for (int base = blockIdx.x * 256; base < n; base += stride) {
-        const int cnt = n - base < 256 ? n - base : 256;
-        if (group_on) { // block-uniform: skip blocks that only hold untouched groups
+    if (stream_all && first < n) ahead = records_issue<64>(surfels + first, n - first < 64 ? n - first : 64, lane);
+    for (int base = first; base < n; base += stride) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        if (group_on) { // wave-uniform: skip records that only belong to untouched groups
             const int g0 = warp_group_of(group_offsets, n_groups, base), g1 = warp_group_of(group_offsets, n_groups, base + cnt - 1);
             bool any = false;
             for (int g = g0; g <= g1; g++) any |= group_on[g] != 0;
             if (!any) continue;
         }
-        const int n_vec = (cnt * 11 + 3) >> 2; // 44-byte records: a block of 256 starts 16-byte aligned
-        const float4 *src = reinterpret_cast<const float4 *>(surfels + base);
-        float4 *dst = reinterpret_cast<float4 *>(surfels + base);
-        float4 *lds4 = reinterpret_cast<float4 *>(s_rec);
-        const bool whole = cnt == 256 || ((cnt * 11) & 3) == 0;
         if (stream_all) {
-            records_land(s_rec, ahead, surfels + base, cnt, tid);
+            records_land<64>(s_w, ahead, surfels + base, cnt, lane);
         } else {
-            for (int v = tid; v < n_vec; v += 256) {
-                if (whole || v < n_vec - 1) lds4[v] = src[v];
-                else { // ragged last vector of the array: dword by dword
-                    const float *s1 = reinterpret_cast<const float *>(surfels + base);
-                    for (int e = v * 4; e < cnt * 11; e++) s_rec[e] = s1[e];
-                }
-            }
+            const RecRegs now = records_issue<64>(surfels + base, cnt, lane);
+            records_land<64>(s_w, now, surfels + base, cnt, lane);
         }
-        __syncthreads();
+        wave_lds_sync();
         if (stream_all && base + stride < n)
-            ahead = records_issue(surfels + base + stride, n - base - stride < 256 ? n - base - stride : 256, tid);
-        if (tid < cnt) {
+            ahead = records_issue<64>(surfels + base + stride, n - base - stride < 64 ? n - base - stride : 64, lane);
+        if (lane < cnt) {
             const float *m = mats ? mats : single.m;
             bool on = true;
             int g = 0;
             if (group_offsets) {
-                g = warp_group_of(group_offsets, n_groups, base + tid);
+                g = warp_group_of(group_offsets, n_groups, base + lane);
                 m = mats + 16 * g;
                 if (group_on) on = group_on[g] != 0;
             }
             if (on) {
-                float *r = s_rec + tid * 11;
+                float *r = s_w + lane * 11;
                 const float p[3] = {r[0], r[1], r[2]}, v[3] = {r[3], r[4], r[5]};
                 float o[3], w[3];
                 xform_point(m, p, o);
                 xform_dir(m, v, w);
                 r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
                 r[3] = w[0]; r[4] = w[1]; r[5] = w[2];
-                if (cloud && base + tid != group_offsets[g + 1] - 1) cloud[base + tid] = make_float4(o[0], o[1], o[2], r[7]);
+                if (cloud && base + lane != group_offsets[g + 1] - 1) cloud[base + lane] = make_float4(o[0], o[1], o[2], r[7]);
             }
         }
-        __syncthreads();
-        for (int v = tid; v < n_vec; v += 256) {
-            if (whole || v < n_vec - 1) rec_store(dst + v, lds4[v]);
-            else {
-                float *d1 = reinterpret_cast<float *>(surfels + base);
-                for (int e = v * 4; e < cnt * 11; e++) d1[e] = s_rec[e];
-            }
-        }
-        __syncthreads();
+        wave_lds_sync();
+        records_from_lds<64>(surfels + base, s_w, cnt, lane);
+        wave_lds_sync();
     }
 }
 
@@ -2336,7 +2331,13 @@ __global__ void k_append(const DeviceCtx ctx, int n) {
 }
 
 // workgroups of `kernel` the current device holds at once (occupancy x CUs), cached per kernel and device
-template <typename K> static int resident_blocks(K kernel, int block_size) {
+// Workgroups of `kernel` for a grid-stride pass over the map: what the device holds at once, or `per_cu_wanted` per CU if
+// that is fewer.  The map-sized kernels are fastest BELOW full occupancy -- every wave keeps a trip of records in flight,
+// and past the bytes in flight that cover the memory latency more of them only queue up behind each other (8 M surfels:
+// k_warp 146 us with 8 workgroups per CU, 136 with 4, 195 with 2; k_fuse_surfels 222 us with 5, 203 with 3, 215 with 2;
+// the same order at 2 M).
+constexpr int kWarpBlocksPerCu = 4, kFuseBlocksPerCu = 3;
+template <typename K> static int resident_blocks(K kernel, int block_size, int per_cu_wanted) {
     static int cached[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -2344,7 +2345,7 @@ template <typename K> static int resident_blocks(K kernel, int block_size) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_size, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached[dev] = per_cu * cus;
+        cached[dev] = (per_cu < per_cu_wanted ? per_cu : per_cu_wanted) * cus;
     }
     return cached[dev];
 }
@@ -2354,7 +2355,7 @@ hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, c
                        float4 *d_cloud) {
     int blocks = (n_upper + 255) / 256;
     if (blocks < 1) blocks = 1;
-    const int cap = resident_blocks(k_warp, 256); // see launch_frame, fuse_blocks
+    const int cap = resident_blocks(k_warp, 256, kWarpBlocksPerCu);
     if (blocks > cap) blocks = cap;
     WarpMat one;
     for (int i = 0; i < 16; i++) one.m[i] = single16 ? single16[i] : 0.0f;
@@ -2500,12 +2501,11 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     if (batched) hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitLarge>), dim3(kFitLargeBlocks), dim3(64));
     hipLaunchStage(k_seed_finish<false>, k_seed_finish<true>, g_seed_thr, dim3(256));
     DSM_MARK();
-    // grid-stride over the map with as many workgroups as the device holds at once: with more, the ones that start
-    // late run all their trips after the others have finished theirs (2 048 against 1 280 resident cost 76 instead of
-    // 61 us at 2 M surfels)
+    // grid-stride over the map with no more workgroups than the device holds at once (the ones that start late would run
+    // all their trips after the others have finished theirs), and fewer than that: see resident_blocks
     int fuse_blocks = (map_upper_bound + 255) / 256;
     if (fuse_blocks < 1) fuse_blocks = 1;
-    const int fuse_cap = batched ? resident_blocks(k_fuse_surfels<true>, 256) : resident_blocks(k_fuse_surfels<false>, 256);
+    const int fuse_cap = batched ? resident_blocks(k_fuse_surfels<true>, 256, kFuseBlocksPerCu) : resident_blocks(k_fuse_surfels<false>, 256, kFuseBlocksPerCu);
     if (fuse_blocks > fuse_cap) fuse_blocks = fuse_cap;
     hipLaunchStage(k_fuse_surfels<false>, k_fuse_surfels<true>, dim3(fuse_blocks), dim3(256));
     DSM_MARK();
