@@ -166,6 +166,7 @@ struct dsm_handle {
     bool fence_pending = false;
     int64_t frames_submitted = 0, frames_done = 0;
     int map_upper = 0; // host-side upper bound of the resident map size
+    bool tail_large = false; // the map may exceed k_frame_tail's one-workgroup path: graphs hold the tail's extra workgroups
     bool map_valid = false;
     hipEvent_t ev[kNumStages + 2];
     bool have_events = false;
@@ -277,6 +278,28 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
 
 int fuse_grid_bound(const dsm_handle *h) { return h->hc.cap; }
 
+// What launch_frame is told about the map size for k_frame_tail (dsm_device.h): graphs are captured once, so they carry
+// the capacity -- but only from the moment the map can be large (map_grows); eager launches pass the running bound.
+int tail_bound(const dsm_handle *h) { return h->tail_large ? h->hc.cap : 0; }
+
+// Before `frames` more frames are enqueued: once the map can pass the size k_frame_tail's one-workgroup path takes, the
+// captured graphs that hold the tail are dropped (once per handle) and come back with its extra workgroups.
+int map_grows(dsm_handle *h, int frames) {
+    if (h->tail_large) return DSM_OK;
+    if ((int64_t)h->map_upper + (int64_t)(frames - 1) * h->hc.n_seed <= (int64_t)kTailFastWords * 64) return DSM_OK;
+    h->tail_large = true;
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // (the graphs may be in flight)
+    for (int i = 0; i < 4; i++)
+        if (h->g_group_map[i]) { (void)hipGraphExecDestroy(h->g_group_map[i]); h->g_group_map[i] = nullptr; }
+    for (int p = 0; p < kMaxPipes; p++)
+        for (int i = 0; i < 2; i++) {
+            dsm_handle::Pipe &pp = h->pipe[p];
+            if (pp.g_map[i]) { (void)hipGraphExecDestroy(pp.g_map[i]); pp.g_map[i] = nullptr; }
+            if (pp.g_all[i]) { (void)hipGraphExecDestroy(pp.g_all[i]); pp.g_all[i] = nullptr; }
+        }
+    return DSM_OK;
+}
+
 // grow-only device scratch of the handle (tail copy of dsm_store_erase, argument blocks of the warps)
 int scratch_reserve(dsm_handle *h, size_t need) {
     if (need <= h->store_tmp_bytes) return DSM_OK;
@@ -293,7 +316,7 @@ int capture(dsm_handle *h, hipStream_t st, const DeviceCtx &ctx, bool with_compa
     if (*out) return DSM_OK;
     hipGraph_t g = nullptr;
     HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    hipError_t le = launch_frame(ctx, fuse_grid_bound(h), with_compaction, st, nullptr, lo, hi);
+    hipError_t le = launch_frame(ctx, fuse_grid_bound(h), tail_bound(h), with_compaction, st, nullptr, lo, hi);
     hipError_t ce = hipStreamEndCapture(st, &g);
     if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
     if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
@@ -307,13 +330,14 @@ int capture(dsm_handle *h, hipStream_t st, const DeviceCtx &ctx, bool with_compa
 // frame's pipeline stream, fuse + tail on the map stream
 int submit_frame(dsm_handle *h, bool with_compaction) {
     h->shadow_n = -1;
+    if (int rc = map_grows(h, 1)) return rc;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
     const bool eager = (h->cfg.flags & DSM_FLAG_NO_GRAPH) != 0;
     const int wc = with_compaction ? 1 : 0;
     if (h->n_pipe == 1) { // everything on the map stream, one graph
         if (eager) {
-            hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, nullptr);
+            hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         } else {
             int rc = capture(h, h->stream, pp.ctx, with_compaction, 0, kNumStages - 1, &pp.g_all[wc]);
@@ -329,7 +353,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
             h->params_pending &= ~(1ull << p);
         }
         if (eager) {
-            hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, pp.stream, nullptr, 0, kLastSuperpixelStage);
+            hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, pp.stream, nullptr, 0, kLastSuperpixelStage);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         } else {
             int rc = capture(h, pp.stream, pp.ctx, with_compaction, 0, kLastSuperpixelStage, &pp.g_sp);
@@ -339,7 +363,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
         HIP_TRY(h, hipEventRecord(pp.ev_sp, pp.stream));
         HIP_TRY(h, hipStreamWaitEvent(h->stream, pp.ev_sp, 0));
         if (eager) {
-            hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
+            hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         } else {
             int rc = capture(h, h->stream, pp.ctx, with_compaction, kLastSuperpixelStage + 1, kNumStages - 1, &pp.g_map[wc]);
@@ -373,6 +397,7 @@ bool group_path(const dsm_handle *h) {
 int submit_group(dsm_handle *h) {
     h->shadow_n = -1;
     const int G = group_size(h);
+    if (int rc = map_grows(h, G)) return rc;
     const int p0 = (int)(h->frames_submitted % h->n_pipe); // a multiple of G
     const int half = p0 / G;
     // group k runs on the stream of pipeline k: HIP spreads streams over its four hardware queues in creation order, and
@@ -397,7 +422,7 @@ int submit_group(dsm_handle *h) {
     if (!h->g_group[half]) {
         hipGraph_t g = nullptr;
         HIP_TRY(h, hipStreamBeginCapture(lead.stream, hipStreamCaptureModeThreadLocal));
-        const hipError_t le = launch_frame(lead.ctx, fuse_grid_bound(h), true, lead.stream, nullptr, 0, kLastSuperpixelStage,
+        const hipError_t le = launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, lead.stream, nullptr, 0, kLastSuperpixelStage,
                                            h->d_pipe_ctxs + p0, G);
         const hipError_t ce = hipStreamEndCapture(lead.stream, &g);
         if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
@@ -416,7 +441,7 @@ int submit_group(dsm_handle *h) {
         HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         hipError_t le = hipSuccess;
         for (int j = 0; j < G && le == hipSuccess; j++)
-            le = launch_frame(h->pipe[p0 + j].ctx, fuse_grid_bound(h), true, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
+            le = launch_frame(h->pipe[p0 + j].ctx, fuse_grid_bound(h), tail_bound(h), true, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
         const hipError_t ce = hipStreamEndCapture(h->stream, &g);
         if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
         if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
@@ -444,7 +469,7 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
         h->params_pending &= ~kSerialBit;
     }
-    hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, ev, lo, hi);
+    hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, ev, lo, hi);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     if (h->n_pipe > 1) {
         HIP_TRY(h, hipEventRecord(pp.ev_map, h->stream));
@@ -465,6 +490,7 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
 // ---- drop-in calls: everything on the map stream, in two parts, so that the host can look at the caller's surfel
 // array while the superpixel stages (which need the frame only) already run
 int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
+    if (int rc = map_grows(h, 1)) return rc;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
     if (h->n_pipe > 1 && (h->params_pending & kSerialBit)) {
@@ -473,7 +499,7 @@ int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
     }
     const int lo = map_part ? kLastSuperpixelStage + 1 : 0, hi = map_part ? kNumStages - 1 : kLastSuperpixelStage;
     if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
-        hipError_t e = launch_frame(pp.ctx, h->map_upper, with_compaction, h->stream, nullptr, lo, hi);
+        hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr, lo, hi);
         if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     } else {
         hipGraphExec_t *g = map_part ? &pp.g_map[with_compaction ? 1 : 0] : &pp.g_sp_main;
@@ -777,6 +803,8 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &c.hole_mask, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.wave_prefix, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.holes, (size_t)c.cap));
+    c.n_hole_chunk = c.cap / (64 * kTailChunkWords) + 1;
+    CREATE_TRY(dev_alloc(h, &c.hole_chunk, (size_t)c.n_hole_chunk + 2));
     int32_t *scalars = nullptr; // shared: n_local, n_local_next, n_new, n_holes, status
     CREATE_TRY(dev_alloc(h, &scalars, 64));
     c.n_local = scalars + 8; c.n_local_next = scalars + 16; c.n_new = scalars + 24;
@@ -1480,6 +1508,7 @@ struct dsm_batch {
     hipEvent_t ev[kNumStages + 2];
     bool have_events = false;
     int cap_max = 0;
+    bool tail_large = false; // a handle's map may exceed k_frame_tail's one-workgroup path (see map_grows)
     std::string err;
 };
 
@@ -1528,6 +1557,20 @@ int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots,
     return DSM_OK;
 }
 // the handles' bookkeeping after m frames were enqueued on the batch stream; their streams wait for the batch
+// map_grows for a batch: its one graph holds the tails of all its handles
+int batch_map_grows(dsm_batch *b, int m) {
+    if (b->tail_large) return DSM_OK;
+    bool large = false;
+    for (const dsm_handle *h : b->hs) large = large || (int64_t)h->map_upper + (int64_t)(m - 1) * h->hc.n_seed > (int64_t)kTailFastWords * 64;
+    if (!large) return DSM_OK;
+    b->tail_large = true;
+    if (b->graph) {
+        BHIP_TRY(b, hipStreamSynchronize(b->stream));
+        (void)hipGraphExecDestroy(b->graph);
+        b->graph = nullptr;
+    }
+    return DSM_OK;
+}
 int batch_advance(dsm_batch *b, int m) {
     BHIP_TRY(b, hipEventRecord(b->ev_out, b->stream));
     for (dsm_handle *h : b->hs) {
@@ -1623,10 +1666,11 @@ int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slot
         if (m > kParamRing / 2) m = kParamRing / 2;
         int rc = batch_stage(b, n_frames, i, m, slots, ref_idx, poses16);
         if (rc) return rc;
+        if ((rc = batch_map_grows(b, m))) return rc;
         if (!b->graph) {
             hipGraph_t g = nullptr;
             BHIP_TRY(b, hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-            const hipError_t le = launch_frame(h0->pipe[0].ctx, b->cap_max, true, b->stream, nullptr, 0, kNumStages - 1, b->d_ctxs, (int)b->hs.size());
+            const hipError_t le = launch_frame(h0->pipe[0].ctx, b->cap_max, b->tail_large ? b->cap_max : 0, true, b->stream, nullptr, 0, kNumStages - 1, b->d_ctxs, (int)b->hs.size());
             const hipError_t ce = hipStreamEndCapture(b->stream, &g);
             if (le != hipSuccess) return bfail(b, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
             if (ce != hipSuccess) return bfail(b, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
@@ -1664,7 +1708,8 @@ int dsm_batch_replay_timed(dsm_batch *b, int32_t n_frames, const int32_t *slots,
     for (int i = 0; i < n_frames; i++) {
         int rc = batch_stage(b, n_frames, i, 1, slots, ref_idx, poses16);
         if (rc) return rc;
-        const hipError_t e = launch_frame(h0->pipe[0].ctx, b->cap_max, true, b->stream, b->ev, 0, kNumStages - 1, b->d_ctxs, n);
+        if ((rc = batch_map_grows(b, 1))) return rc;
+        const hipError_t e = launch_frame(h0->pipe[0].ctx, b->cap_max, b->tail_large ? b->cap_max : 0, true, b->stream, b->ev, 0, kNumStages - 1, b->d_ctxs, n);
         if (e != hipSuccess) return bfail(b, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         if ((rc = batch_advance(b, 1))) return rc;
         if ((rc = dsm_batch_synchronize(b))) return rc;

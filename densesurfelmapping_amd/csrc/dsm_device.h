@@ -100,6 +100,11 @@ struct DeviceCtx {
     int32_t *wave_prefix; // [cap/64] exclusive prefix of popcounts
     int32_t *holes;       // [cap] ascending indices of deleted slots
     int32_t *n_holes;
+    // large maps (more than kTailFastWords * 64 surfels): holes per chunk of kTailChunkWords bitmap words, counted by
+    // k_fuse_surfels, for the workgroups of k_frame_tail that list them; [n_hole_chunk] = their ticket counter,
+    // [n_hole_chunk + 1] = the map size the frame started with.  All zero between frames (the tail's last workgroup resets them).
+    int32_t *hole_chunk;
+    int32_t n_hole_chunk;
     // sequencing
     const FrameParams *params;
     int32_t n_params;
@@ -111,6 +116,11 @@ struct DeviceCtx {
     long long *stamps; // [5 kernels][n_seed][8]
 };
 
+// k_frame_tail: a thread owns kScanWords words of the hole bitmap per round, a workgroup kTailChunkWords; maps of up to
+// kTailFastWords * 64 surfels take its one-workgroup fast path
+constexpr int kScanWords = 8, kTailChunkWords = 1024 * kScanWords, kTailFastWords = 4096;
+constexpr int kTailMaxBlocks = 33; // workgroups of k_frame_tail for a large map: one for the new surfels, the rest list holes
+
 constexpr int kStatusCapacity = 1;
 constexpr int kStatusBadPick = 2;
 constexpr int kStatusBadLabels = 4; // a superpixel with more members than its 15 x 15 reach (injected label image)
@@ -121,7 +131,10 @@ constexpr int kStatusBadLabels = 4; // a superpixel with more members than its 1
 constexpr int kNumStages = 16;
 constexpr int kLastSuperpixelStage = 13; // init_seeds .. seed_fit need the frame only; fuse_surfels + frame_tail need the map
 extern const char *const kStageNames[kNumStages];
-hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, bool with_compaction,
+// map_upper_bound sizes the grid-stride pass of k_fuse_surfels (any bound does, the loop covers the map); tail_map_bound
+// must be an upper bound of the map size whenever that exceeds kTailFastWords * 64 (it decides whether k_frame_tail gets
+// the workgroups that list a large map's holes), and may be 0 while the map is known to be smaller.
+hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, int tail_map_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1,
                         const DeviceCtx *d_batch = nullptr, int n_batch = 1);
 

@@ -180,6 +180,7 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DSM_G(wave_prefix);
     DSM_G(holes);
     DSM_G(n_holes);
+    DSM_G(hole_chunk);
     DSM_G(params);
     DSM_G(cursor);
     DSM_G(status);
@@ -1808,6 +1809,10 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
     const float *dep = frame_depth(c, fp);
     const int M = c->n_local[0];
     const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    // a large map's deleted slots are listed by several workgroups of k_frame_tail: they need the holes per chunk of the
+    // bitmap, and the map size this frame started with (the tail's first workgroup moves n_local)
+    const bool big_map = M > kTailFastWords * 64;
+    if (big_map && blk.x == 0 && tid == 0) c->hole_chunk[c->n_hole_chunk + 1] = M;
     FuseConst fc;
     fc.k = c->k; fc.far_d = c->far_d; fc.near_d = c->near_d;
     fc.baseline = c->baseline; fc.disp_err = c->disp_err; fc.min_tol = c->min_tol;
@@ -1881,7 +1886,10 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
             hole = e.update_times == 0;
         }
         const unsigned long long m = __ballot(hole);
-        if (lane == 0) c->hole_mask[base >> 6] = m;
+        if (lane == 0) {
+            c->hole_mask[base >> 6] = m;
+            if (big_map && m) atomicAdd(&c->hole_chunk[base / (64 * kTailChunkWords)], __popcll(m)); // (deletions are rare)
+        }
         wave_lds_sync();
         if (__ballot(changed) != 0) records_from_lds<64>(c->local + base, s_w, cnt, lane); // (stored back only if a surfel of the 64 changed)
         wave_lds_sync();
@@ -1975,42 +1983,49 @@ __device__ __forceinline__ int tail_spawn_list(const DeviceCtx *__restrict__ c, 
 // A thread owns kScanWords consecutive bitmap words per round (two 16-byte loads each pair, coalesced across the block): one
 // block scan orders 8 192 words = 524 288 surfels, so a 2 M-surfel map takes four rounds and an 8 M one sixteen (one word
 // per thread and round: 31 and 122).
-constexpr int kScanWords = 8;
+// One round: the kTailChunkWords words from `base`, holes before them = `run`; returns the holes of the round.
+__device__ __forceinline__ int tail_hole_round(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */, int n_word, int base, int run) {
+    const int v0 = base + (int)threadIdx.x * kScanWords;
+    unsigned long long m[kScanWords];
+#pragma unroll
+    for (int q = 0; q < kScanWords; q += 2) { // (the allocation holds cap / 64 + 1 words, rounded up by dev_alloc's slack)
+        ulonglong2 two = make_ulonglong2(0, 0);
+        if (v0 + q < n_word) two = *reinterpret_cast<const ulonglong2 *>(c->hole_mask + v0 + q);
+        m[q] = two.x;
+        m[q + 1] = v0 + q + 1 < n_word ? two.y : 0ull;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < kScanWords; q++) cnt += __popcll(m[q]);
+    int excl;
+    const int total = block_scan_1024(cnt, excl, s_wave);
+    int o = run + excl;
+#pragma unroll
+    for (int q = 0; q < kScanWords; q++) {
+        if (v0 + q < n_word) {
+            c->wave_prefix[v0 + q] = o;
+            unsigned long long w = m[q];
+            while (w) {
+                const int b = __ffsll((long long)w) - 1;
+                c->holes[o++] = (v0 + q) * 64 + b;
+                w &= w - 1;
+            }
+        }
+    }
+    return total;
+}
 __device__ __forceinline__ int tail_hole_scan(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */, int M) {
     const int n_word = (M + 63) >> 6;
     int run = 0;
-    for (int base = 0; base < n_word; base += 1024 * kScanWords) {
-        const int v0 = base + (int)threadIdx.x * kScanWords;
-        unsigned long long m[kScanWords];
-#pragma unroll
-        for (int q = 0; q < kScanWords; q += 2) { // (the allocation holds cap / 64 + 1 words, rounded up by dev_alloc's slack)
-            ulonglong2 two = make_ulonglong2(0, 0);
-            if (v0 + q < n_word) two = *reinterpret_cast<const ulonglong2 *>(c->hole_mask + v0 + q);
-            m[q] = two.x;
-            m[q + 1] = v0 + q + 1 < n_word ? two.y : 0ull;
-        }
-        int cnt = 0;
-#pragma unroll
-        for (int q = 0; q < kScanWords; q++) cnt += __popcll(m[q]);
-        int excl;
-        const int total = block_scan_1024(cnt, excl, s_wave);
-        int o = run + excl;
-#pragma unroll
-        for (int q = 0; q < kScanWords; q++) {
-            if (v0 + q < n_word) {
-                c->wave_prefix[v0 + q] = o;
-                unsigned long long w = m[q];
-                while (w) {
-                    const int b = __ffsll((long long)w) - 1;
-                    c->holes[o++] = (v0 + q) * 64 + b;
-                    w &= w - 1;
-                }
-            }
-        }
-        run += total;
-    }
+    for (int base = 0; base < n_word; base += kTailChunkWords) run += tail_hole_round(c, s_wave, n_word, base, run);
     if (threadIdx.x == 0) c->n_holes[0] = run;
     return run;
+}
+// sum of the first n per-chunk hole counts of k_fuse_surfels (whole workgroup)
+__device__ __forceinline__ int tail_chunk_holes(const DeviceCtx *__restrict__ c, int *s_wave /* [17] */, int n) {
+    int part = 0, excl;
+    for (int i = threadIdx.x; i < n; i += 1024) part += c->hole_chunk[i];
+    return block_scan_1024(part, excl, s_wave);
 }
 
 // ------------------------------------------------------------------------------ compaction
@@ -2070,7 +2085,7 @@ __device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c, in
 // words of the hole bitmap (thread t owns words 4t .. 4t+3: one block scan orders all holes) -- the spawn list and the
 // refill targets stay in LDS, and the only second trip is the prepared records themselves.  The rare K < k frame (more
 // deleted slots than new surfels: swap-with-last chains) and larger frames / maps take the general path below.
-constexpr int kTailFastSeeds = 8192, kTailFastWords = 4096;
+constexpr int kTailFastSeeds = 8192; // (kTailFastWords: dsm_device.h)
 
 __device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c, int with_compaction, int *s_idx /* [8192] */,
                                                 int *s_refill /* [8192] */, int *s_cnt /* [129] */, int *s_wave /* [17] */, int &M_out) {
@@ -2179,6 +2194,12 @@ __device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c,
     return true;
 }
 
+// A LARGE map (more than kTailFastWords * 64 surfels) with compaction is worked by all the workgroups of the launch (one
+// per kTailChunkWords words of its bitmap, at most kTailMaxBlocks): the hole list is what grows with the map -- a round
+// of the scan per 524 288 surfels, each a chain of trips to memory, sixteen of them at 8 M.  k_fuse_surfels has counted the
+// holes of every chunk, so every chunk's place in the list is known up front and the chunks are listed independently;
+// workgroup 0 orders the new surfels meanwhile.  Whichever workgroup finishes LAST (a ticket taken behind a device-scope
+// fence) sees all the lists and does the compaction and the commit.  Nobody waits for anybody.
 template <bool BATCH> __global__ __launch_bounds__(1024) void k_frame_tail(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int with_compaction) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
@@ -2187,29 +2208,65 @@ template <bool BATCH> __global__ __launch_bounds__(1024) void k_frame_tail(const
     __shared__ int s_cnt[kMaxSeedRounds * 16 + 1];
     __shared__ int s_wave[17];
     __shared__ int s_idx[kTailFastSeeds], s_refill[kTailFastSeeds];
-    int M = 0;
-    if (c->n_seed <= kTailFastSeeds) {
-        if (frame_tail_fast(c, with_compaction, s_idx, s_refill, s_cnt, s_wave, M)) return;
-        __syncthreads(); // K < k, or a larger map: start over on the general path
+    __shared__ int s_last;
+    const int n_blk = gridDim.x;
+    int M = 0, K = 0;
+    if (blk.x > 0) { // hole lists of a large map
+        M = c->hole_chunk[c->n_hole_chunk + 1]; // (0 unless k_fuse_surfels saw a large map)
+        if (!with_compaction || M <= kTailFastWords * 64) return;
+        const int n_word = (M + 63) >> 6;
+        for (int ch = blk.x - 1; ch * kTailChunkWords < n_word; ch += n_blk - 1) {
+            const int before = tail_chunk_holes(c, s_wave, ch);
+            tail_hole_round(c, s_wave, n_word, ch * kTailChunkWords, before);
+        }
     } else {
-        M = c->n_local[0];
+        if (c->n_seed <= kTailFastSeeds) {
+            if (frame_tail_fast(c, with_compaction, s_idx, s_refill, s_cnt, s_wave, M)) return;
+            __syncthreads(); // K < k, or a larger map: start over on the general path
+        } else {
+            M = c->n_local[0];
+        }
+        K = tail_spawn_list(c, s_cnt);
+        const bool large = M > kTailFastWords * 64;
+        if (!(large && with_compaction && n_blk > 1)) { // everything here
+            int k = 0;
+            if (with_compaction) k = tail_hole_scan(c, s_wave, M);
+            __threadfence_block(); // the lists were written by this workgroup (same CU): no device-scope write-back needed
+            __syncthreads();
+            if (with_compaction) {
+                tail_compact(c, M, K, k);
+            } else { // FusionFunctions::fuse_initialize_map hands the new surfels back separately
+                for (int j = threadIdx.x; j < K; j += 1024) c->fresh[j] = c->spawn_rec[c->spawn_idx[j]];
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (with_compaction) c->n_local[0] = c->n_local_next[0];
+                c->cursor[0] = c->cursor[0] + 1;
+            }
+            if (large) // k_fuse_surfels counted, nobody else looks: back to zero for the next frame
+                for (int i = threadIdx.x; i < c->n_hole_chunk + 2; i += 1024) c->hole_chunk[i] = 0;
+            return;
+        }
     }
-    const int K = tail_spawn_list(c, s_cnt);
-    int k = 0;
-    if (with_compaction) k = tail_hole_scan(c, s_wave, M);
-    __threadfence_block(); // the lists were written by this workgroup (same CU): no device-scope write-back needed
+    // ---- large map: the last workgroup to get here finishes the frame
+    __threadfence();
     __syncthreads();
-    if (with_compaction) {
-        tail_compact(c, M, K, k);
-    } else { // FusionFunctions::fuse_initialize_map hands the new surfels back separately
-        for (int j = threadIdx.x; j < K; j += 1024) c->fresh[j] = c->spawn_rec[c->spawn_idx[j]];
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd(&c->hole_chunk[c->n_hole_chunk], 1) == n_blk - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    K = load_coherent(c->n_new);
+    const int k = tail_chunk_holes(c, s_wave, c->n_hole_chunk);
+    if (threadIdx.x == 0) c->n_holes[0] = k;
+    tail_compact(c, M, K, k);
     __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (with_compaction) c->n_local[0] = c->n_local_next[0];
+        c->n_local[0] = c->n_local_next[0];
         c->cursor[0] = c->cursor[0] + 1;
     }
+    for (int i = threadIdx.x; i < c->n_hole_chunk + 2; i += 1024) c->hole_chunk[i] = 0;
 }
 
 // ------------------------------------------------------------------------------ map deformation
@@ -2422,7 +2479,7 @@ const char *const kStageNames[kNumStages] = {
 
 // d_batch != nullptr: the kernels take their context from d_batch[blockIdx.z], z < n_batch (handles of equal geometry
 // advancing in lockstep: one launch per kernel for all of them); hc is then any one of them (grid sizes).
-hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_compaction,
+hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_bound, bool with_compaction,
                         hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi, const DeviceCtx *d_batch, int n_batch) {
     int stage = 0;
     hipError_t err = hipSuccess;
@@ -2509,7 +2566,15 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, bool with_comp
     if (fuse_blocks > fuse_cap) fuse_blocks = fuse_cap;
     hipLaunchStage(k_fuse_surfels<false>, k_fuse_surfels<true>, dim3(fuse_blocks), dim3(256));
     DSM_MARK();
-    hipLaunchStage(k_frame_tail<false>, k_frame_tail<true>, dim3(1), dim3(1024), with_compaction ? 1 : 0);
+    // (a map that may be beyond the tail's one-workgroup path gets a workgroup per chunk of its hole bitmap on top; they
+    // leave at once while the map is small, but starting them is not free -- 8 us per launch for eight handles -- so
+    // the callers pass 0 until the map can be that large, dsm_api.hip: tail_bound)
+    int tail_blocks = 1;
+    if (with_compaction && tail_map_bound > kTailFastWords * 64) {
+        tail_blocks = 1 + (tail_map_bound / 64 + kTailChunkWords) / kTailChunkWords;
+        if (tail_blocks > kTailMaxBlocks) tail_blocks = kTailMaxBlocks;
+    }
+    hipLaunchStage(k_frame_tail<false>, k_frame_tail<true>, dim3(tail_blocks), dim3(1024), with_compaction ? 1 : 0);
     DSM_MARK();
     if (ev) { // empty interval: what a pair of event records costs by itself
         err = hipEventRecord(ev[stage], st);

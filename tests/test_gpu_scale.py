@@ -265,6 +265,59 @@ def test_batched_large_maps_headline_regime(mods, gold):
     ff.close()
 
 
+def test_map_grows_past_the_tail_fast_path(mods):
+    """A map that starts just below 262 144 surfels and grows past it while frames are being replayed: the graphs captured
+    for the small map (k_frame_tail with one workgroup) are dropped and come back with the workgroups that list a large
+    map's holes (dsm_api.hip, map_grows); k_fuse_surfels starts counting holes per chunk.  One handle with one graph per
+    frame, one with frame groups, and a batch of eight, each against the port oracle after every chunk of frames."""
+    api, synth, ob = mods
+    case = scale_cases.LARGE_MAP
+    cam = getattr(synth, case["camera"])
+    scene = synth.Scene(**case["scene"])
+    n = 9
+    frames = list(synth.sequence(cam, scene, case["base_frames"] + n))[case["base_frames"]:]
+    big, _ = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, case)
+    start = scale_cases.large_map_variant(big[:259000], {"stale": 0.004, "dead": 0.002}, synth)
+    slots, refs, poses = api.FusionFunctions.pack_replay(list(range(n)), [f[4] for f in frames], [f[3] for f in frames])
+    oracle = ob.PortOracle(cam)
+    models, m = [], start
+    for f in frames:
+        m, _ = oracle.fuse_map(f[4], f[1], f[2], f[3], m)
+        models.append(m)
+    sizes = [len(start)] + [len(x) for x in models]
+    assert sizes[0] < 262144 and sizes[3] < 262144 < sizes[-3], sizes  # crosses in the middle of the replay
+
+    def start_handle(depth):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=600_000, pipeline_depth=depth)
+        for i, f in enumerate(frames):
+            ff.frame_upload(i, f[1], f[2])
+        ff.map_upload(start.astype(api.SURFEL_DTYPE))
+        return ff
+
+    for depth in (1, 16):
+        ff = start_handle(depth)
+        done = 0
+        for chunk in (2, 4, 3):
+            ff.replay_enqueue(slots[done:done + chunk], refs[done:done + chunk], poses[done:done + chunk])
+            done += chunk
+            got = ff.map_download()
+            assert fields_equal(got, models[done - 1].astype(api.SURFEL_DTYPE)) == [], (depth, done)
+        ff.close()
+    handles = [start_handle(1) for _ in range(8)]
+    batch = api.Batch(handles)
+    done = 0
+    for chunk in (3, 3, 3):
+        pk = api.Batch.pack([(slots[done:done + chunk], refs[done:done + chunk], poses[done:done + chunk])] * len(handles))
+        batch.replay_enqueue(pk[0], pk[1], pk[2], chunk)
+        batch.synchronize()
+        done += chunk
+        for b, ff in enumerate(handles):
+            assert fields_equal(ff.map_download(), models[done - 1].astype(api.SURFEL_DTYPE)) == [], (b, done)
+    batch.close()
+    for ff in handles:
+        ff.close()
+
+
 def _random_rigid(rng, scale=0.05):
     a = rng.normal(size=3) * scale
     th = np.linalg.norm(a)
