@@ -226,6 +226,22 @@ def cpu_baseline(cam, scene, rendered, period, lo, hi, budget_s=25.0):
                       f"per frame, {'10 std::threads per stage as in the reference' if kind == 'reference' else 'scalar C restatement'}"}
 
 
+PMC_MAP_8M = os.path.join(ROOT, "profiles", "r03_pmc_map_kernels_8m.json")
+
+
+def pmc_8m(kernel, us):
+    """Memory-side bytes per launch of a map-sized kernel at 8 M surfels (committed rocprofv3 --pmc passes), next to the
+    live duration: what the memory system moved, gathers included, as opposed to the 88 algorithmic bytes per surfel."""
+    try:
+        row = json.load(open(PMC_MAP_8M))[kernel]
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+    moved = row["fetch_bytes_corrected"] + row["write_bytes"]
+    return {"traffic": {"read_bytes": row["fetch_bytes_corrected"], "write_bytes": row["write_bytes"], "l2_hit_rate": row["l2_hit_rate"],
+                        "memory_side_GBps": round(moved / us / 1e3, 1), "of_achievable_6300_GBps": round(moved / us / 1e3 / 6300.0, 3),
+                        "source": "profiles/r03_pmc_map_kernels_8m.json (rocprofv3 --pmc, FETCH_SIZE corrected x2 for gfx950)"}}
+
+
 def event_timer(torch, ff):
     """HIP events on the handle's own stream (torch.cuda.Event only sees torch's current stream by default)."""
     stream = torch.cuda.ExternalStream(ff.stream())
@@ -689,6 +705,7 @@ def main():
                           "achieved_GBps": round(88 * m_8 / us_f8 / 1e3, 1), "hbm_frac": round(88 * m_8 / us_f8 / 1e3 / HBM_PEAK_GBS, 4),
                           "frame_tail_us": round(us_t8, 1),
                           "timing": "HIP events around the kernel on the handle's stream (eager replay, 8 frames)"}
+        out["fuse_8M"].update(pmc_8m("k_fuse_surfels", us_f8))
         ff.close()
         # the warp kernel on a working set the Infinity Cache cannot hold: 8 M surfels = 352 MB read + 352 MB written
         n_w = 8_000_000
@@ -705,6 +722,7 @@ def main():
         out["map_warp_8M"] = {"surfels": n_w, "us": round(us_w8, 1), "alg_bytes": 88 * n_w, "achieved_GBps": round(88 * n_w / us_w8 / 1e3, 1),
                               "hbm_frac": round(88 * n_w / us_w8 / 1e3 / HBM_PEAK_GBS, 4),
                               "timing": "HIP events around 30 back-to-back dsm_map_warp calls (704 MB moved per call)"}
+        out["map_warp_8M"].update(pmc_8m("k_warp", us_w8))
         ff.close()
     if extras:
         # BASELINE configs[3]: live callback, 640x480 RGB-D constants, one frame at a time: host frame in

@@ -2249,13 +2249,21 @@ template <bool BATCH> __global__ __launch_bounds__(1024) void k_frame_tail(const
             return;
         }
     }
-    // ---- large map: the last workgroup to get here finishes the frame
-    __threadfence();
+    // ---- large map: the last workgroup to get here finishes the frame.  The workgroups sit on different XCDs, whose L2s
+    // are not coherent with each other: every wave's stores drained, then one agent-scope release (L2 write-back) before
+    // the ticket; the last arriver's agent-scope acquire (drops this CU's L1 and the L2's non-local lines) before it
+    // reads what the others wrote, with plain vector loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&c->hole_chunk[c->n_hole_chunk], 1) == n_blk - 1 ? 1 : 0;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (restated: the compiler may drop the fence's own wait)
+        const bool last = __hip_atomic_fetch_add(&c->hole_chunk[c->n_hole_chunk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_blk - 1;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_last = last ? 1 : 0;
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     K = load_coherent(c->n_new);
     const int k = tail_chunk_holes(c, s_wave, c->n_hole_chunk);
     if (threadIdx.x == 0) c->n_holes[0] = k;
