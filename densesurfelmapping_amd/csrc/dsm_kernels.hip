@@ -286,6 +286,79 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
     c->tmin[s] = -1; // fused = stable = false
 }
 
+// The same with ONE LANE PER SEED, for launches batched over many handles: sixteen lanes per seed are 440 workgroups per
+// handle, each a chain of three dependent trips to memory (cursor -> params -> pixels) that ends in one 16-byte store per
+// sixteen lanes -- 56 000 workgroups per launch of 128 handles, 153 us of wave turnover.  Here a lane reads its seed's
+// centre pixel, and only a wave that holds a seed without depth there walks windows: every such lane its own, row by row
+// from the last to the first so that the lowest row and column with a depth is what remains (FF.cpp:600-626).
+template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds_lanes(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    const int tid = threadIdx.x;
+    const int s = blk.x * 256 + tid;
+    if (blk.x == 0 && tid < kSweeps * kWorkers) c->first_empty[tid] = kIntMax;
+    if (blk.x == 0 && tid == 0) c->work_count[0] = c->fit_big_count[0] = 0;
+    if (blk.x == 0 && tid < 2 * kSweeps) c->rest_count[tid] = 0;
+    // first kernel of the frame: resolve the params ring once and publish the result (FrameCur)
+    const FrameParams &fp = c->params[(unsigned)(c->cursor[0] * c->cursor_mul + c->cursor_add) % (unsigned)c->n_params];
+    const uint8_t *img = c->img_base + (int64_t)fp.slot * c->slot_elems;
+    const float *dep = c->depth_base + (int64_t)fp.slot * c->slot_elems;
+    if (blk.x == 0 && tid < 64) {
+        FrameCur *wc = c->cur;
+        const int t = tid;
+        if (t < 16) wc->p.pose[t] = fp.pose[t];
+        else if (t < 32) wc->p.inv[t - 16] = fp.inv[t - 16];
+        else if (t == 32) { wc->p.ref_idx = fp.ref_idx; wc->p.slot = fp.slot; }
+        else if (t == 33) wc->img = img;
+        else if (t == 34) wc->dep = dep;
+    }
+    const int w = c->w, h = c->h, pitch = c->pitch;
+    const bool live = s < c->n_seed;
+    const int sc = live ? s : 0;
+    int gx, gy;
+    seed_cell(c, sc, gx, gy);
+    int ix = gx * kCell + kCell / 2, iy = gy * kCell + kCell / 2;
+    if (ix > w - 1) ix = w - 1;
+    if (iy > h - 1) iy = h - 1;
+    float md = dep[iy * pitch + ix];
+    const float mi = (float)img[iy * pitch + ix];
+    const bool need = live && md < flt_above(0.01); // (double)md < 0.01
+    if (__ballot(need) != 0) {
+        const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
+        const int x_lo = wx0 < 0 ? 0 : wx0, x_hi = wx0 + 2 * kCell > w - 1 ? w - 1 : wx0 + 2 * kCell;
+        const int y_lo = wy0 < 0 ? 0 : wy0, y_hi = wy0 + 2 * kCell > h - 1 ? h - 1 : wy0 + 2 * kCell;
+        bool hit = false;
+        float first = 0.0f;
+#pragma unroll 4
+        for (int r = 2 * kCell - 1; r >= 0; r--) {
+            const int y = wy0 + r;
+            const bool row_in = need && y >= y_lo && y < y_hi;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int x = wx0 + 4 * q; // multiple of 4: 16-byte aligned, and never straddles x = 0
+                v[q] = (row_in && x >= 0) ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 3; q >= 0; q--) {
+                const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                for (int t = 3; t >= 0; t--) {
+                    const int x = wx0 + 4 * q + t;
+                    if (row_in && x >= x_lo && x < x_hi && e[t] > flt_below(0.01)) { hit = true; first = e[t]; }
+                }
+            }
+        }
+        if (need && hit) md = first;
+    }
+    if (!live) return;
+    c->core[s] = make_float4((float)ix, (float)iy, mi, md);
+    c->inv_depth[s] = 1.0 / (double)md;
+    c->tmin[s] = -1; // fused = stable = false
+}
+
 // ------------------------------------------------------------------------------ assign
 // One thread per column of FOUR pixels (a 4 x 4 quadrant of a cell shares its <= 2 x 2 candidate seeds: they are fetched
 // once per thread), a 64x16-pixel tile per block; the <=10x4 seeds a tile can pick from are staged in LDS.  FIRST sweep:
@@ -2524,7 +2597,8 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
     const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
-    hipLaunchStage(k_init_seeds<false>, k_init_seeds<true>, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256));
+    if (lanes) hipLaunchStage(k_init_seeds_lanes<true>, k_init_seeds_lanes<true>, g_seed_thr, dim3(256));
+    else hipLaunchStage(k_init_seeds<false>, k_init_seeds<true>, dim3((S + kInitSeedsPerBlock - 1) / kInitSeedsPerBlock), dim3(256));
     DSM_MARK();
     for (int sweep = 0; sweep < kSweeps; sweep++) {
         if (sweep == 0) {
