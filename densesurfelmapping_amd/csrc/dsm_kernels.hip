@@ -2379,6 +2379,9 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
     const int n = n_ptr ? n_ptr[0] : n_fixed;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     // a wave moves its own 64 records through its quarter of the tile (see k_fuse_surfels: no workgroup barrier)
+    float one[16]; // the one matrix of a launch without groups: wave-uniform, read once
+#pragma unroll
+    for (int q = 0; q < 16; q++) one[q] = group_offsets ? 0.0f : (mats ? mats[q] : single.m[q]);
     float *s_w = s_rec + wv * 64 * 11;
     // without untouched groups to skip, every block is read: its records are fetched one trip ahead (records_issue)
     const bool stream_all = group_on == nullptr;
@@ -2404,13 +2407,17 @@ __global__ __launch_bounds__(256) void k_warp(dsm_surfel *__restrict__ surfels, 
         if (stream_all && base + stride < n)
             ahead = records_issue<64>(surfels + base + stride, n - base - stride < 64 ? n - base - stride : 64, lane);
         if (lane < cnt) {
-            const float *m = mats ? mats : single.m;
             bool on = true;
             int g = 0;
+            float m[16]; // this record's matrix, in registers (the address of a kernel argument would put it in scratch memory)
             if (group_offsets) {
                 g = warp_group_of(group_offsets, n_groups, base + lane);
-                m = mats + 16 * g;
                 if (group_on) on = group_on[g] != 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) m[q] = mats[16 * g + q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) m[q] = one[q];
             }
             if (on) {
                 float *r = s_w + lane * 11;
@@ -2472,9 +2479,10 @@ __global__ void k_append(const DeviceCtx ctx, int n) {
 // Workgroups of `kernel` for a grid-stride pass over the map: what the device holds at once, or `per_cu_wanted` per CU if
 // that is fewer.  The map-sized kernels are fastest BELOW full occupancy -- every wave keeps a trip of records in flight,
 // and past the bytes in flight that cover the memory latency more of them only queue up behind each other (8 M surfels:
-// k_warp 146 us with 8 workgroups per CU, 136 with 4, 195 with 2; k_fuse_surfels 222 us with 5, 203 with 3, 215 with 2;
-// the same order at 2 M).
-constexpr int kWarpBlocksPerCu = 4, kFuseBlocksPerCu = 3;
+// k_warp 146 us with 8 workgroups per CU, 136 with 4, 195 with 2 -- and, once its matrix stopped living in scratch memory,
+// 125 with 3, 120.5 with 4, 118 with 5, 120 with 6; k_fuse_surfels 222 us with 5, 203 with 3, 215 with 2; the same order
+// at 2 M).
+constexpr int kWarpBlocksPerCu = 5, kFuseBlocksPerCu = 3;
 template <typename K> static int resident_blocks(K kernel, int block_size, int per_cu_wanted) {
     static int cached[64] = {0};
     int dev = 0;
