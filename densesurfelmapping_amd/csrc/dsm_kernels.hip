@@ -722,6 +722,33 @@ template <typename Fetch> __device__ __forceinline__ float huber_pass_lanes(Fetc
     return huber_newton_step(a, b);
 }
 
+// The same pass over a list held in REGISTERS (k_update_seeds_rest: the list of a queued seed is read once and serves
+// four passes).  Same operations in the same order as huber_pass_lanes; the loop is unrolled so that every v[] index is a
+// constant, and leaves at the first block of eight beyond the longest list of the wave.
+constexpr int kRestRegs = 128; // >= kLaneCap
+__device__ __forceinline__ float huber_pass_regs(const float (&v)[kRestRegs], int lim, float md, double hr) {
+    const float hr_above = flt_above(hr);
+    const unsigned hr_lo = (unsigned)__double_as_longlong(hr), hr_hi = (unsigned)(__double_as_longlong(hr) >> 32);
+    float a = 0.0f;
+    int n_tail = 0;
+#pragma unroll
+    for (int i = 0; i < kRestRegs; i += 8) {
+        if (__ballot(i < lim) == 0) break;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float r = i + q < lim ? md - v[i + q] : 0.0f;
+            const bool core = fabsf(r) < hr_above; // (double)r < hr && (double)r > -hr
+            const float a_core = a + 2 * r;
+            const double step = __longlong_as_double((long long)(((unsigned long long)(r > 0 ? hr_hi : hr_hi ^ 0x80000000u) << 32) | hr_lo));
+            const float a_tail = (float)((double)a + step);
+            a = core ? a_core : a_tail;
+            n_tail += core ? 0 : 1;
+        }
+    }
+    const float b = (float)(2 * (lim - n_tail)); // the reference adds 2.0f per core element: exact
+    return huber_newton_step(a, b);
+}
+
 // ---- update_seeds, ONE LANE PER SEED: a wave takes 64 consecutive seeds (launches batched over handles).
 // The wave-per-seed form above spends most of its instructions on work one lane could do: window addressing, the label
 // apply, the ballot / rank compaction and two wave reductions are repeated by every wave for every window, and the
@@ -989,10 +1016,26 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     const double hr = c->huber;
     const unsigned src0 = (((unsigned)blk.x * kLaneCap) << 8) + ((unsigned)lane << 2);
     const int n_max = __builtin_amdgcn_readfirstlane(wave_max_int(live ? nd : 0));
+    // The lists into registers, all loads in flight at once: this kernel is pure latency (a few waves per handle between
+    // two stages that wait for it), and with the list re-read from memory by every pass -- one block of eight ahead --
+    // each of up to 64 blocks waited for most of a trip to the L2: 28 us, whatever the batch.
+    static_assert(kRestRegs >= kLaneCap, "list registers");
+    float v[kRestRegs];
+#pragma unroll
+    for (int b = 0; b < kRestRegs; b += 16) {
+        if (b < n_max) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[b + q] = ld_off(c->rest_list, src0 + ((unsigned)(b + q < n_max ? b + q : n_max - 1) << 8));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[b + q] = 0.0f;
+        }
+    }
     bool run = live;
+#pragma unroll 1
     for (int it = 1; it < 5; it++) {
         if (__ballot(run) == 0) break;
-        const float delta = huber_pass_lanes([&](int i) { return ld_off(c->rest_list, src0 + ((unsigned)(i < n_max ? i : 0) << 8)); }, run ? nd : 0, md, hr);
+        const float delta = huber_pass_regs(v, run ? nd : 0, md, hr);
         if (run) md = md + delta;
         if (fabsf(delta) < flt_above(0.01)) run = false; // (double)delta < 0.01 && (double)delta > -0.01
     }
