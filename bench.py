@@ -133,13 +133,19 @@ class ClockSampler:
     """Shader clock during the timed region: a thread reads the current sclk from sysfs (pp_dpm_sclk marks the active level
     with '*') every 20 ms.  None if the file is not there (no amdgpu sysfs in the container)."""
 
-    def __init__(self):
+    def __init__(self, pci_bdf=None):
         import glob
-        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.samples, self._stop, self._thr = [], False, None
+        # the node's sysfs lists every GPU of the machine, whichever one this process was given: go by PCI address
+        base = f"/sys/bus/pci/devices/{pci_bdf}" if pci_bdf and os.path.isdir(f"/sys/bus/pci/devices/{pci_bdf}") else None
+        self.device = pci_bdf if base else None
+        pat = base if base else "/sys/class/drm/card*/device"
+        self.files = sorted(glob.glob(pat + "/pp_dpm_sclk"))
+        self.mfiles = sorted(glob.glob(pat + "/pp_dpm_mclk"))
+        self.pfiles = sorted(glob.glob(pat + "/hwmon/hwmon*/power1_average"))
+        self.samples, self.msamples, self.psamples, self._stop, self._thr = [], [], [], False, None
 
-    def _read(self):
-        for f in self.files[:1]:
+    def _read(self, files=None):
+        for f in (self.files if files is None else files)[:1]:
             try:
                 for line in open(f):
                     if "*" in line:
@@ -157,6 +163,14 @@ class ClockSampler:
                     v = self._read()
                     if v:
                         self.samples.append(v)
+                    m = self._read(self.mfiles)
+                    if m:
+                        self.msamples.append(m)
+                    for f in self.pfiles[:1]:
+                        try:
+                            self.psamples.append(float(open(f).read()) / 1e6)
+                        except (OSError, ValueError):
+                            pass
                     time.sleep(0.02)
             self._thr = threading.Thread(target=loop, daemon=True)
             self._thr.start()
@@ -169,6 +183,13 @@ class ClockSampler:
 
     def ghz(self):
         return round(float(np.median(self.samples)) / 1e3, 3) if self.samples else None
+
+    def other(self):
+        """memory clock (GHz) and board power (W) over the same samples, where sysfs has them"""
+        return {"sysfs_device": self.device or "first card of the node (PCI address of the HIP device not found: the clocks may be another GPU's)",
+                "memory_clock_ghz": round(float(np.median(self.msamples)) / 1e3, 3) if self.msamples else None,
+                "power_w_median": round(float(np.median(self.psamples)), 1) if self.psamples else None,
+                "shader_clock_ghz_min_max": [round(min(self.samples) / 1e3, 3), round(max(self.samples) / 1e3, 3)] if self.samples else None}
 
 
 def cpu_model():
@@ -426,7 +447,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    clock = ClockSampler()
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except (AttributeError, RuntimeError):
+        bdf = None
+    clock = ClockSampler(bdf)
     t0 = time.perf_counter()
     with clock:
         run(lo_t, hi_t)
@@ -831,6 +857,7 @@ def main():
     out["superpixel_stage_hbm_frac"] = round(fps * (9 * n_pix + 60 * n_seed) / 1e9 / (HBM_PEAK_GBS * world), 5)
     if args.mode == "batched":
         out["valu_issue"] = valu_issue(fps / world, clock.ghz())
+        out["clocks"] = clock.other()
 
     if rank == 0:
         print(json.dumps(out))
