@@ -1,3 +1,10 @@
+#!/usr/bin/env python
+"""Which hardware queues the batched frame kernels of a traced bench run went to (rocprofv3 --kernel-trace csv):
+
+    python tools/queue_stats.py gpurun_out/prof_<tag>
+
+prints {queue id: (launches, busy ms, stream ids)} for the kernels launched over 8 handles.  Four queues with equal shares
+are what the reserved batch streams (dsm_api.hip, BatchStreamPool) are for; two batches on one queue run one after the other."""
 import csv, glob, sys
 from collections import defaultdict
 d = sys.argv[1]
