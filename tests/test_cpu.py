@@ -841,3 +841,23 @@ def test_eigen_last_place_exposure_is_bounded(oracle_built):
             assert abs(row["final_surfels"] - row["final_surfels_baseline"]) <= 2, (name, row)
             if row["first_frame_with_other_counts"] is None:
                 assert row["integer_fields_changed"] == 0 and row["max_rel_float_drift"] < 1e-3, (name, row)
+
+
+def test_shipped_sources_carry_no_hooks():
+    """The product translation units: no environment lookups, no compile-time experiment switches, no CUDA shims, and
+    nothing from oracle/ -- experiments live as patches under tools/_exp, the oracle is test infrastructure."""
+    import re
+    csrc = os.path.join(ROOT, "densesurfelmapping_amd", "csrc")
+    banned = [r"\bgetenv\s*\(", r"#\s*if(def)?\s+.*DSM_(EXP|TILED|XCD_STRIPS|RELAXED|BATCH_XCD)", r"__HIP_PLATFORM_(AMD|NVIDIA)__", r"cuda_runtime",
+              r"#\s*include\s*[\"<][^\">]*oracle"]
+    seen = []
+    for name in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, name)).read()
+        for pat in banned:
+            for m in re.finditer(pat, text):
+                seen.append((name, text.count("\n", 0, m.start()) + 1, m.group(0)))
+    assert seen == [], seen
+    for name in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        path = os.path.join(ROOT, "include", name)
+        if os.path.isfile(path):
+            assert "oracle" not in open(path).read(), name
