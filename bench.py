@@ -22,6 +22,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -202,6 +203,17 @@ def cpu_model():
     return "unknown"
 
 
+def canon_bytes(a: np.ndarray) -> bytes:
+    """the bytes of a surfel array with every NaN replaced by one canonical NaN (the reference's arithmetic does not
+    define a NaN's sign or payload; everything else is compared bit for bit)"""
+    a = np.ascontiguousarray(a)
+    words = a.view(np.uint32).reshape(len(a), -1).copy()
+    for i, name in enumerate(a.dtype.names):
+        if a.dtype[name].kind == "f":
+            words[np.isnan(a[name]), i] = 0x7FC00000
+    return words.tobytes()
+
+
 def cpu_baseline(cam, scene, rendered, period, lo, hi, budget_s=25.0):
     """The reference's own fusion_functions.cpp (oracle/_ref, real 10-thread schedule) if its prebuilt library is
     present, else our C restatement (1 thread).  Replays the subsequence from frame 0 (untimed up to `lo`: that builds
@@ -316,10 +328,11 @@ def main():
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("DSM_BENCH_HOST_THREADS", "4")),
                     help="host threads enqueueing graph replays (each drives streams/threads handles)")
     ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("DSM_BENCH_PIPELINE_DEPTH", "0")),
-                    help="frames of one subsequence whose superpixel stages may be in flight (0 = library default)")
+                    help="frames of one subsequence whose superpixel stages may be in flight (0 = 1: the B subsequences already fill the queues)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs beside the headline (drop-in, configs 4 and 5, node)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed form against the CPU oracle")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -790,6 +803,111 @@ def main():
                                  "note": "image_input + depth_input + orb_results_input per frame (drift_free_poses 10, keyframe every 5, "
                                          "loop closure with warp of active and inactive surfels at frame %d); host-inclusive" % period}
         node.close()
+
+    if rank == 0 and world == 1 and args.mode == "batched" and not args.no_verify:
+        # What was timed, checked: fresh handles, the timed region's own form -- every batch of subsequences enqueued by
+        # its own host thread on its own stream, all batches in flight at once -- over the first frames of every plan, and
+        # the maps of one handle per batch against the CPU oracle's replay of the same frames (untimed; the oracle is the
+        # checker here, nothing of it runs inside any timed region).
+        from oracle.bindings import SURFEL_DTYPE as O_DTYPE, PortOracle
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+        n_v = 12
+        hs = [make_handle(b, pipeline_depth=1) for b in range(B)]
+        bts = [api.Batch([hs[b] for b in grp]) for grp in groups_b]
+
+        def one_v(g):
+            for c0 in range(0, n_v, 5):  # several enqueue calls per batch, like the timed region's chunks
+                c1 = min(n_v, c0 + 5)
+                sb, rb, pb, nn = api.Batch.pack([(plans[b][0][c0:c1], plans[b][1][c0:c1], plans[b][2][c0:c1]) for b in groups_b[g]])
+                bts[g].replay_enqueue(sb, rb, pb, nn)
+        list(pool.map(one_v, range(n_bat)))
+        for bt_ in bts:
+            bt_.synchronize()
+        checked, bad = [], []
+        for g in range(n_bat):
+            b = groups_b[g][g % len(groups_b[g])]
+            got = hs[b].map_download()
+            orc, lo_ = PortOracle(cam), np.zeros(0, O_DTYPE)
+            for t in range(n_v):
+                img, dep = rendered[scene_of[b]][(t + phase_of[b]) % period]
+                lo_, _ = orc.fuse_map(t // 5, img, dep, scenes[scene_of[b]].pose(t + phase_of[b]), lo_)
+            same = len(got) == len(lo_) and canon_bytes(got) == canon_bytes(lo_)
+            checked.append({"subsequence": b, "batch": g, "surfels": int(len(got)), "oracle_surfels": int(len(lo_)), "equal": bool(same)})
+            if not same:
+                bad.append(b)
+        out["verified"] = not bad
+        out["verification"] = {"form": f"{n_bat} batches of {len(groups_b[0])} subsequences in flight at once, one host thread and stream per batch (the timed region's form)",
+                               "frames_per_subsequence": n_v, "checked": checked,
+                               "against": "oracle/liboracle_port.so (C restatement of fusion_functions.cpp + surfel_map.cpp:1077-1109), NaN-canonical bytes of the whole map"}
+        for bt_ in bts:
+            bt_.close()
+        for h_ in hs:
+            h_.close()
+
+    if extras and args.mode == "batched":
+        # Frames arriving from the HOST (what a KITTI replay does: the reference receives every frame through image_input /
+        # depth_input, surfel_map.cpp:83-101) instead of a scene period resident in HBM: the same batched replay with 2 x C
+        # frame slots per subsequence, chunk k + 1 sent up from page-locked memory (dsm_frame_upload_async, one transfer
+        # per plane) while chunk k is being fused; maps resident.  The resident headline needs 29 k x 2.37 MB = 69 GB/s of
+        # input -- more than the PCIe link carries -- so this leg is what a real log can sustain.
+        C_s, k_s, w_s = 16, min(K, 10), 3
+        hs = [api.FusionFunctions.from_camera(cam, device=device, frame_slots=2 * C_s, surfel_capacity=capacity, pipeline_depth=1) for _ in range(B)]
+        pins = []
+        for sc in range(n_scene):
+            pf = api.PinnedFrames(hs[0], period)
+            for i, (img, dep) in enumerate(rendered[sc]):
+                pf.set(i, img, dep)
+            pins.append(pf)
+        for h_ in hs:
+            h_.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        bts = [api.Batch([hs[b] for b in grp]) for grp in groups_b]
+        n_chunks = (w_s + k_s) * F // C_s
+
+        def send(g, k):  # chunk k of every subsequence of batch g -> slot half k & 1
+            for b in groups_b[g]:
+                pf = pins[scene_of[b]]
+                for i in range(C_s):
+                    t = (k * C_s + i + phase_of[b]) % period
+                    hs[b].frame_upload_async((k & 1) * C_s + i, pf.image(t), pf.depth(t))
+
+        def chunk_plan(b, k):
+            lo, hi = k * C_s, (k + 1) * C_s
+            return (np.ascontiguousarray([(k & 1) * C_s + i for i in range(C_s)], np.int32), plans[b][1][lo:hi], plans[b][2][lo:hi])
+
+        def stream_batch(g, k0, k1):
+            for k in range(k0, k1):
+                if k + 1 < n_chunks:
+                    send(g, k + 1)  # BEFORE chunk k is enqueued: ordered behind chunk k - 1, whose slots it overwrites
+                sb, rb, pb, nn = api.Batch.pack([chunk_plan(b, k) for b in groups_b[g]])
+                bts[g].replay_enqueue(sb, rb, pb, nn)
+
+        for g in range(n_bat):
+            send(g, 0)
+        k_w = w_s * F // C_s
+        list(pool.map(lambda g: stream_batch(g, 0, k_w), range(n_bat)))
+        for bt_ in bts:
+            bt_.synchronize()
+        t_s = time.perf_counter()
+        list(pool.map(lambda g: stream_batch(g, k_w, n_chunks), range(n_bat)))
+        for bt_ in bts:
+            bt_.synchronize()
+        dt_s = time.perf_counter() - t_s
+        fps_s = B * (n_chunks - k_w) * C_s / dt_s
+        frame_bytes = pins[0].pitch * cam.height * 5  # what one frame moves over the link: pitched image + depth rows
+        out["streamed_input"] = {"value": round(fps_s, 1), "unit": "frames/s", "pcie_GBps": round(fps_s * frame_bytes / 1e9, 2),
+                                 "bytes_per_frame": int(frame_bytes), "fraction_of_resident_rate": round(fps_s / fps, 3),
+                                 "frame_slots_per_subsequence": 2 * C_s, "chunk_frames": C_s, "subsequences": B, "steps": k_s,
+                                 "mean_live_surfels": round(float(np.mean([h_.map_size() for h_ in hs]))),
+                                 "note": "the headline's batched replay with the frames streamed from page-locked host memory "
+                                         "(dsm_frame_upload_async on the device's upload stream, double-buffered in chunks) instead of "
+                                         "resident in HBM; maps resident; parity: tests/test_gpu_scale.py::test_long_sequence_streamed_input"}
+        for bt_ in bts:
+            bt_.close()
+        for h_ in hs:
+            h_.frame_uploads_wait()
+            h_.close()
+        for pf in pins:
+            pf.close()
 
     if extras and args.mode == "batched":
         # The headline replay never lets a keyframe leave the window, so its maps grow without bound and 83 % of B_alg is

@@ -44,12 +44,13 @@ DSM_MAX_STAGES = 32
 ABI_SYMBOLS = (
     "dsm_abi_version", "dsm_config_init", "dsm_create", "dsm_destroy", "dsm_last_error",
     "dsm_host_alloc", "dsm_host_free",
-    "dsm_fuse_initialize_map", "dsm_fuse_map",
+    "dsm_fuse_initialize_map", "dsm_fuse_map", "dsm_fuse_initialize_map_inv", "dsm_fuse_map_inv",
+    "dsm_fuse_frame_resident_inv", "dsm_replay_enqueue_inv", "dsm_batch_replay_enqueue_inv",
     "dsm_map_upload", "dsm_map_size", "dsm_map_capacity", "dsm_map_download", "dsm_map_copy_to_device",
     "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
     "dsm_store_deactivate", "dsm_store_activate", "dsm_store_erase", "dsm_store_warp", "dsm_store_size",
     "dsm_store_download",
-    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
+    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_frame_pitch", "dsm_frame_upload_async", "dsm_frame_uploads_wait", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
     "dsm_batch_replay_timed",
@@ -107,6 +108,12 @@ def load_library():
     lib.dsm_fuse_initialize_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int32,
                                             _vp, C.c_int32, _vp]
     lib.dsm_fuse_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_int32, _vp]
+    lib.dsm_fuse_initialize_map_inv.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_int32,
+                                                _vp, C.c_int32, _vp]
+    lib.dsm_fuse_map_inv.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_int32, _vp]
+    lib.dsm_fuse_frame_resident_inv.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
+    lib.dsm_replay_enqueue_inv.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp]
+    lib.dsm_batch_replay_enqueue_inv.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp]
     lib.dsm_map_upload.argtypes = [_vp, _vp, C.c_int32]
     lib.dsm_map_size.argtypes = [_vp, _vp]
     lib.dsm_map_capacity.argtypes = [_vp, _vp]
@@ -124,6 +131,9 @@ def load_library():
     lib.dsm_store_download.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp]
     lib.dsm_frame_upload.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
     lib.dsm_frame_upload_device.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
+    lib.dsm_frame_pitch.argtypes = [_vp, _vp]
+    lib.dsm_frame_upload_async.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
+    lib.dsm_frame_uploads_wait.argtypes = [_vp]
     lib.dsm_fuse_frame_resident.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.dsm_replay_enqueue.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
     lib.dsm_synchronize.argtypes = [_vp]
@@ -154,6 +164,15 @@ def load_library():
 
 def _ptr(a):
     return a.ctypes.data_as(_vp)
+
+
+def _inv_ptr(inv_pose):
+    """the caller's own world->cam matrix (4x4 row-major numpy, or 16 column-major floats) as a pointer, or NULL"""
+    if inv_pose is None:
+        return None, None
+    a = np.asarray(inv_pose, np.float32)
+    a = pose_to_colmajor(a) if a.shape == (4, 4) else np.ascontiguousarray(a.reshape(16))
+    return a, _ptr(a)
 
 
 def pose_to_colmajor(pose) -> np.ndarray:
@@ -227,29 +246,32 @@ class FusionFunctions:
         return image, depth
 
     # fusion_functions.h:88-94: returns (local_surfels updated, new_surfels)
-    def fuse_initialize_map(self, reference_frame_index, image, depth, pose, local_surfels):
+    # inv_pose: the caller's own pose.inverse() (FF.cpp:59), see dsm_fuse_map_inv in include/dsm.h; None = the library's closed form
+    def fuse_initialize_map(self, reference_frame_index, image, depth, pose, local_surfels, inv_pose=None):
         image, depth = self._frame_args(image, depth)
         pose_cm = pose_to_colmajor(pose)
+        _keep, inv = _inv_ptr(inv_pose)
         local = np.ascontiguousarray(local_surfels, SURFEL_DTYPE).copy()
         fresh = np.zeros(self.n_seed, SURFEL_DTYPE)
         n_new = C.c_int32(0)
-        self._check(self._lib.dsm_fuse_initialize_map(
+        self._check(self._lib.dsm_fuse_initialize_map_inv(
             self._h, reference_frame_index, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0],
-            _ptr(pose_cm), _ptr(local), len(local), _ptr(fresh), len(fresh), C.byref(n_new)))
+            _ptr(pose_cm), inv, _ptr(local), len(local), _ptr(fresh), len(fresh), C.byref(n_new)))
         return local, fresh[: n_new.value].copy()
 
     # SurfelMap::fuse_map (surfel_map.cpp:1060-1113): returns (local_surfels after compaction, n_new)
-    def fuse_map(self, reference_frame_index, image, depth, pose, local_surfels):
+    def fuse_map(self, reference_frame_index, image, depth, pose, local_surfels, inv_pose=None):
         image, depth = self._frame_args(image, depth)
         pose_cm = pose_to_colmajor(pose)
+        _keep, inv = _inv_ptr(inv_pose)
         cap = len(local_surfels) + self.n_seed
         buf = np.zeros(cap, SURFEL_DTYPE)
         buf[: len(local_surfels)] = local_surfels
         n_local = C.c_int32(len(local_surfels))
         n_new = C.c_int32(0)
-        self._check(self._lib.dsm_fuse_map(
+        self._check(self._lib.dsm_fuse_map_inv(
             self._h, reference_frame_index, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0],
-            _ptr(pose_cm), _ptr(buf), C.byref(n_local), cap, C.byref(n_new)))
+            _ptr(pose_cm), inv, _ptr(buf), C.byref(n_local), cap, C.byref(n_new)))
         return buf[: n_local.value].copy(), n_new.value
 
     def fuse_map_inplace(self, reference_frame_index, image, depth, pose, buf, n_local):
@@ -354,13 +376,31 @@ class FusionFunctions:
         self._check(self._lib.dsm_frame_upload(self._h, slot, _ptr(image), image.strides[0], _ptr(depth),
                                                depth.strides[0]))
 
+    def frame_pitch(self) -> int:
+        n = C.c_int32(0)
+        self._check(self._lib.dsm_frame_pitch(self._h, C.byref(n)))
+        return n.value
+
+    def frame_upload_async(self, slot, image, depth):
+        """dsm_frame_upload_async: `image` / `depth` are views of PAGE-LOCKED memory (PinnedFrames below) that stay
+        untouched until frame_uploads_wait(); rows with the slot pitch go up as one transfer per plane."""
+        if image.dtype != np.uint8 or depth.dtype != np.float32 or image.shape != (self.height, self.width) or depth.shape != image.shape:
+            raise TypeError("image must be uint8 [H,W], depth float32 [H,W]")
+        if image.strides[1] != 1 or depth.strides[1] != 4:
+            raise ValueError("rows must be contiguous")
+        self._check(self._lib.dsm_frame_upload_async(self._h, slot, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0]))
+
+    def frame_uploads_wait(self):
+        self._check(self._lib.dsm_frame_uploads_wait(self._h))
+
     def frame_upload_device(self, slot, image_ptr, img_step, depth_ptr, depth_step):
         self._check(self._lib.dsm_frame_upload_device(self._h, slot, _vp(image_ptr), img_step, _vp(depth_ptr),
                                                       depth_step))
 
-    def fuse_frame_resident(self, slot, reference_frame_index, pose):
+    def fuse_frame_resident(self, slot, reference_frame_index, pose, inv_pose=None):
         pose_cm = pose_to_colmajor(pose)
-        self._check(self._lib.dsm_fuse_frame_resident(self._h, slot, reference_frame_index, _ptr(pose_cm)))
+        _keep, inv = _inv_ptr(inv_pose)
+        self._check(self._lib.dsm_fuse_frame_resident_inv(self._h, slot, reference_frame_index, _ptr(pose_cm), inv))
 
     @staticmethod
     def pack_replay(slots, ref_idx, poses):
@@ -369,9 +409,14 @@ class FusionFunctions:
         poses_cm = np.ascontiguousarray(np.asarray(poses, np.float32).transpose(0, 2, 1)).reshape(len(slots), 16)
         return slots, ref_idx, poses_cm
 
-    def replay_enqueue(self, slots, ref_idx, poses_cm):
-        """slots/ref_idx int32 [n], poses_cm float32 [n,16] column-major (see pack_replay)."""
-        self._check(self._lib.dsm_replay_enqueue(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm)))
+    def replay_enqueue(self, slots, ref_idx, poses_cm, inv_poses_cm=None):
+        """slots/ref_idx int32 [n], poses_cm float32 [n,16] column-major (see pack_replay); inv_poses_cm: the caller's own
+        inverses in the same layout, or None."""
+        inv = None
+        if inv_poses_cm is not None:
+            inv_poses_cm = np.ascontiguousarray(inv_poses_cm, np.float32).reshape(len(slots), 16)
+            inv = _ptr(inv_poses_cm)
+        self._check(self._lib.dsm_replay_enqueue_inv(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm), inv))
 
     def synchronize(self):
         self._check(self._lib.dsm_synchronize(self._h))
@@ -446,6 +491,47 @@ class FusionFunctions:
         return {st.name[i].decode(): (st.ms[i], st.launches[i]) for i in range(st.n_stages)}, st.frames
 
 
+class PinnedFrames:
+    """n frames in page-locked host memory (dsm_host_alloc), rows laid out with a handle's slot pitch, pad columns zero:
+    image(i) / depth(i) are [H,W] views that dsm_frame_upload_async moves in one transfer per plane."""
+
+    def __init__(self, ff: FusionFunctions, n: int):
+        self._lib = load_library()
+        self.n, self.h, self.w, self.pitch = n, ff.height, ff.width, ff.frame_pitch()
+        self._bytes_img, self._bytes_dep = self.pitch * self.h, self.pitch * self.h * 4
+        p = _vp()
+        rc = self._lib.dsm_host_alloc(C.byref(p), n * (self._bytes_img + self._bytes_dep))
+        if rc:
+            raise DsmError(rc, "dsm_host_alloc")
+        self._p = p
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n * (self._bytes_img + self._bytes_dep),))
+        raw[:] = 0
+        self._img = raw[: n * self._bytes_img].reshape(n, self.h, self.pitch)
+        self._dep = raw[n * self._bytes_img:].view(np.float32).reshape(n, self.h, self.pitch)
+
+    def image(self, i):
+        return self._img[i, :, : self.w]
+
+    def depth(self, i):
+        return self._dep[i, :, : self.w]
+
+    def set(self, i, image, depth):
+        self.image(i)[...] = image
+        self.depth(i)[...] = depth
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._img = self._dep = None
+            self._lib.dsm_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Batch:
     """Handles of equal image size on one device advancing in lockstep: every kernel of a frame is launched once for all
     of them (include/dsm.h, dsm_batch_*).  The handles keep their own maps and frame slots and stay usable on their own
@@ -485,8 +571,12 @@ class Batch:
                 np.ascontiguousarray(np.concatenate([p[1] for p in plans]), np.int32),
                 np.ascontiguousarray(np.concatenate([p[2] for p in plans]), np.float32), n)
 
-    def replay_enqueue(self, slots, ref_idx, poses_cm, n_frames):
-        self._check(self._lib.dsm_batch_replay_enqueue(self._b, n_frames, _ptr(slots), _ptr(ref_idx), _ptr(poses_cm)))
+    def replay_enqueue(self, slots, ref_idx, poses_cm, n_frames, inv_poses_cm=None):
+        inv = None
+        if inv_poses_cm is not None:
+            inv_poses_cm = np.ascontiguousarray(inv_poses_cm, np.float32).reshape(len(slots), 16)
+            inv = _ptr(inv_poses_cm)
+        self._check(self._lib.dsm_batch_replay_enqueue_inv(self._b, n_frames, _ptr(slots), _ptr(ref_idx), _ptr(poses_cm), inv))
 
     def synchronize(self):
         self._check(self._lib.dsm_batch_synchronize(self._b))

@@ -32,8 +32,10 @@ constexpr uint64_t kSerialBit = 1ull << 63;
 constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 
 constexpr int kBatchStreams = 4;
-void batch_streams_reserve(int device); // see BatchStreamPool
+hipError_t batch_streams_reserve(int device); // see BatchStreamPool
 hipStream_t batch_stream_at(int device, int i);
+hipStream_t device_upload_stream(int device); // asynchronous frame uploads of every handle on the device (dsm_frame_upload_async)
+constexpr uint64_t kBatchBit = 1ull << 62;    // up_pending: a batch stream has not waited for this handle's latest upload yet
 
 } // namespace
 
@@ -164,7 +166,13 @@ struct dsm_handle {
     // of its throughput): uploads that follow one wait for ev_fence, recorded once behind the batch
     hipEvent_t ev_fence = nullptr;
     bool fence_pending = false;
+    // dsm_frame_upload_async: ev_up = this handle's latest asynchronous upload has landed (recorded on the device's upload
+    // stream); up_pending = which consumers have not been ordered behind it yet (bit p: pipeline p, kSerialBit: the map
+    // stream, kBatchBit: a batch stream)
+    hipEvent_t ev_up = nullptr;
+    uint64_t up_pending = 0;
     int64_t frames_submitted = 0, frames_done = 0;
+    int batches_joined = 0; // dsm_batch_create copied this handle's context: it must not change any more
     int map_upper = 0; // host-side upper bound of the resident map size
     bool tail_large = false; // the map may exceed k_frame_tail's one-workgroup path: graphs hold the tail's extra workgroups
     bool map_valid = false;
@@ -227,14 +235,17 @@ int reserve_params(dsm_handle *h, int n) {
     return DSM_OK;
 }
 
-int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16) {
+// inv16: the caller's own world -> cam matrix (pose.inverse() of ITS matrix library, FF.cpp:59), or nullptr: the closed
+// form of dsm_math.h
+int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16, const float *inv16 = nullptr) {
     if (slot < 0 || slot >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slot, h->hc.n_slots);
     int rc = reserve_params(h, 1);
     if (rc) return rc;
     const int ring = (int)(h->frames_submitted % kParamRing);
     FrameParams &fp = h->h_params[ring];
     memcpy(fp.pose, pose16, sizeof fp.pose);
-    inverse4<float>(fp.pose, fp.inv); // FF.cpp:59
+    if (inv16) memcpy(fp.inv, inv16, sizeof fp.inv);
+    else inverse4<float>(fp.pose, fp.inv); // FF.cpp:59
     fp.ref_idx = ref_idx;
     fp.slot = slot;
     fp.pad[0] = fp.pad[1] = 0;
@@ -250,7 +261,7 @@ int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16) {
 
 // stage the params of up to n consecutive frames with one host-to-device copy; returns how many
 // were staged (limited by the ring's wrap-around point)
-int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t *ref_idx, const float *poses16, int *staged) {
+int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t *ref_idx, const float *poses16, const float *inv_poses16, int *staged) {
     const int ring = (int)(h->frames_submitted % kParamRing);
     int m = n < kParamRing - ring ? n : kParamRing - ring;
     if (m > kParamRing / 2) m = kParamRing / 2;
@@ -260,7 +271,8 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
         if (slots[i] < 0 || slots[i] >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slots[i], h->hc.n_slots);
         FrameParams &fp = h->h_params[ring + i];
         memcpy(fp.pose, poses16 + 16 * (size_t)i, sizeof fp.pose);
-        inverse4<float>(fp.pose, fp.inv); // FF.cpp:59
+        if (inv_poses16) memcpy(fp.inv, inv_poses16 + 16 * (size_t)i, sizeof fp.inv);
+        else inverse4<float>(fp.pose, fp.inv); // FF.cpp:59
         fp.ref_idx = ref_idx[i];
         fp.slot = slots[i];
         fp.pad[0] = fp.pad[1] = 0;
@@ -273,6 +285,15 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
         h->params_pending = ~0ull;
     }
     *staged = m;
+    return DSM_OK;
+}
+
+// Order `st` behind this handle's latest asynchronous frame upload, once per consumer (`bits` = the consumer's bits of
+// up_pending, see dsm_handle).
+int wait_uploads(dsm_handle *h, hipStream_t st, uint64_t bits) {
+    if (!(h->up_pending & bits)) return DSM_OK;
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_up, 0));
+    h->up_pending &= ~bits;
     return DSM_OK;
 }
 
@@ -312,17 +333,40 @@ int scratch_reserve(dsm_handle *h, size_t need) {
     return DSM_OK;
 }
 
-int capture(dsm_handle *h, hipStream_t st, const DeviceCtx &ctx, bool with_compaction, int lo, int hi, hipGraphExec_t *out) {
-    if (*out) return DSM_OK;
+// Graphs are captured on a stream of their own that lives for the capture only -- never on a stream that executes work.
+// The streams that launch graphs may be shared (the device's reserved per-queue streams serve every batch and every
+// frame-group lead of the process): a capture begun on one of them would swallow whatever another thread enqueues there
+// meanwhile (its hipGraphLaunch / hipStreamWaitEvent would be recorded into this graph, or fail with a capture error).  A
+// graph is not tied to the stream it was captured on; thread-local capture mode keeps other threads' API calls legal.
+// Returns "" or what failed.
+std::string capture_graph(const std::function<hipError_t(hipStream_t)> &launch, hipGraphExec_t *out) {
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return std::string("hipStreamCreateWithFlags (capture stream): ") + hipGetErrorString(e);
+    e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(st);
+        return std::string("hipStreamBeginCapture: ") + hipGetErrorString(e);
+    }
     hipGraph_t g = nullptr;
-    HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    hipError_t le = launch_frame(ctx, fuse_grid_bound(h), tail_bound(h), with_compaction, st, nullptr, lo, hi);
-    hipError_t ce = hipStreamEndCapture(st, &g);
-    if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
-    if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-    hipError_t ie = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
-    if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+    const hipError_t le = launch(st);
+    const hipError_t ce = hipStreamEndCapture(st, &g);
+    (void)hipStreamDestroy(st);
+    if (le != hipSuccess || ce != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        return le != hipSuccess ? std::string("kernel launch during capture: ") + hipGetErrorString(le)
+                                : std::string("hipStreamEndCapture: ") + hipGetErrorString(ce);
+    }
+    const hipError_t ie = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) return std::string("hipGraphInstantiate: ") + hipGetErrorString(ie);
+    return std::string();
+}
+
+int capture(dsm_handle *h, const DeviceCtx &ctx, bool with_compaction, int lo, int hi, hipGraphExec_t *out) {
+    if (*out) return DSM_OK;
+    const std::string err = capture_graph([&](hipStream_t st) { return launch_frame(ctx, fuse_grid_bound(h), tail_bound(h), with_compaction, st, nullptr, lo, hi); }, out);
+    if (!err.empty()) return fail(h, DSM_E_HIP, "%s", err.c_str());
     return DSM_OK;
 }
 
@@ -336,11 +380,12 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
     const bool eager = (h->cfg.flags & DSM_FLAG_NO_GRAPH) != 0;
     const int wc = with_compaction ? 1 : 0;
     if (h->n_pipe == 1) { // everything on the map stream, one graph
+        if (int rc = wait_uploads(h, h->stream, kSerialBit)) return rc;
         if (eager) {
             hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         } else {
-            int rc = capture(h, h->stream, pp.ctx, with_compaction, 0, kNumStages - 1, &pp.g_all[wc]);
+            int rc = capture(h, pp.ctx, with_compaction, 0, kNumStages - 1, &pp.g_all[wc]);
             if (rc) return rc;
             HIP_TRY(h, hipGraphLaunch(pp.g_all[wc], h->stream));
         }
@@ -352,11 +397,12 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
             HIP_TRY(h, hipStreamWaitEvent(pp.stream, h->ev_params, 0));
             h->params_pending &= ~(1ull << p);
         }
+        if (int rc = wait_uploads(h, pp.stream, 1ull << p)) return rc;
         if (eager) {
             hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, pp.stream, nullptr, 0, kLastSuperpixelStage);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         } else {
-            int rc = capture(h, pp.stream, pp.ctx, with_compaction, 0, kLastSuperpixelStage, &pp.g_sp);
+            int rc = capture(h, pp.ctx, with_compaction, 0, kLastSuperpixelStage, &pp.g_sp);
             if (rc) return rc;
             HIP_TRY(h, hipGraphLaunch(pp.g_sp, pp.stream));
         }
@@ -366,7 +412,7 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
             hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
         } else {
-            int rc = capture(h, h->stream, pp.ctx, with_compaction, kLastSuperpixelStage + 1, kNumStages - 1, &pp.g_map[wc]);
+            int rc = capture(h, pp.ctx, with_compaction, kLastSuperpixelStage + 1, kNumStages - 1, &pp.g_map[wc]);
             if (rc) return rc;
             HIP_TRY(h, hipGraphLaunch(pp.g_map[wc], h->stream));
         }
@@ -419,17 +465,12 @@ int submit_group(dsm_handle *h) {
         HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->ev_params, 0));
         h->params_pending &= ~mask;
     }
+    if (int rc = wait_uploads(h, lead.stream, mask)) return rc; // (the same argument as for the params: only `lead` reads these frames' slots before the map stream does)
     if (!h->g_group[half]) {
-        hipGraph_t g = nullptr;
-        HIP_TRY(h, hipStreamBeginCapture(lead.stream, hipStreamCaptureModeThreadLocal));
-        const hipError_t le = launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, lead.stream, nullptr, 0, kLastSuperpixelStage,
-                                           h->d_pipe_ctxs + p0, G);
-        const hipError_t ce = hipStreamEndCapture(lead.stream, &g);
-        if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
-        if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-        const hipError_t ie = hipGraphInstantiate(&h->g_group[half], g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        const std::string err = capture_graph([&](hipStream_t st) {
+            return launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, st, nullptr, 0, kLastSuperpixelStage, h->d_pipe_ctxs + p0, G);
+        }, &h->g_group[half]);
+        if (!err.empty()) return fail(h, DSM_E_HIP, "%s", err.c_str());
     }
     HIP_TRY(h, hipGraphLaunch(h->g_group[half], lead.stream));
     HIP_TRY(h, hipEventRecord(lead.ev_sp, lead.stream));
@@ -437,17 +478,13 @@ int submit_group(dsm_handle *h) {
     // fuse + tail of the G frames, in frame order, as one graph on the map stream (a graph launch per frame costs the
     // map stream more than the two kernels do)
     if (!h->g_group_map[half]) {
-        hipGraph_t g = nullptr;
-        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        hipError_t le = hipSuccess;
-        for (int j = 0; j < G && le == hipSuccess; j++)
-            le = launch_frame(h->pipe[p0 + j].ctx, fuse_grid_bound(h), tail_bound(h), true, h->stream, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
-        const hipError_t ce = hipStreamEndCapture(h->stream, &g);
-        if (le != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
-        if (ce != hipSuccess) return fail(h, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-        const hipError_t ie = hipGraphInstantiate(&h->g_group_map[half], g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ie != hipSuccess) return fail(h, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        const std::string err = capture_graph([&](hipStream_t st) {
+            hipError_t le = hipSuccess;
+            for (int j = 0; j < G && le == hipSuccess; j++)
+                le = launch_frame(h->pipe[p0 + j].ctx, fuse_grid_bound(h), tail_bound(h), true, st, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
+            return le;
+        }, &h->g_group_map[half]);
+        if (!err.empty()) return fail(h, DSM_E_HIP, "%s", err.c_str());
     }
     HIP_TRY(h, hipGraphLaunch(h->g_group_map[half], h->stream));
     // ONE event for the group (every record is a marker packet on the map stream, the serial spine of a sequence)
@@ -469,6 +506,7 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
         h->params_pending &= ~kSerialBit;
     }
+    if (int rc = wait_uploads(h, h->stream, kSerialBit)) return rc;
     hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, ev, lo, hi);
     if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     if (h->n_pipe > 1) {
@@ -497,13 +535,14 @@ int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_params, 0));
         h->params_pending &= ~kSerialBit;
     }
+    if (int rc = wait_uploads(h, h->stream, kSerialBit)) return rc;
     const int lo = map_part ? kLastSuperpixelStage + 1 : 0, hi = map_part ? kNumStages - 1 : kLastSuperpixelStage;
     if (h->cfg.flags & DSM_FLAG_NO_GRAPH) {
         hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr, lo, hi);
         if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     } else {
         hipGraphExec_t *g = map_part ? &pp.g_map[with_compaction ? 1 : 0] : &pp.g_sp_main;
-        int rc = capture(h, h->stream, pp.ctx, with_compaction, lo, hi, g);
+        int rc = capture(h, pp.ctx, with_compaction, lo, hi, g);
         if (rc) return rc;
         HIP_TRY(h, hipGraphLaunch(*g, h->stream));
     }
@@ -752,7 +791,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         }                                                                                 \
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
-    batch_streams_reserve(h->device); // (before any handle stream of this process: see BatchStreamPool)
+    CREATE_TRY(batch_streams_reserve(h->device)); // (before any handle stream of this process: see BatchStreamPool)
     // Depths 12 and 24 run THREE frame groups: their lead streams and the map stream are the device's four reserved
     // streams, one hardware queue each.  (With four groups the map stream shares a queue with one of them, and a stream
     // waiting for an event holds up whatever else is queued behind it on the same hardware queue.)
@@ -913,6 +952,7 @@ void dsm_destroy(dsm_handle *h) {
     for (hipEvent_t e : h->ev_slot)
         if (e) (void)hipEventDestroy(e);
     if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
+    if (h->ev_up) { (void)hipEventSynchronize(h->ev_up); (void)hipEventDestroy(h->ev_up); }
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
@@ -952,6 +992,13 @@ int dsm_stream(dsm_handle *h, void **hip_stream) {
 int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
                             const float *depth, size_t depth_step, const float *pose16, dsm_surfel *local,
                             int32_t n_local, dsm_surfel *new_out, int32_t new_cap, int32_t *n_new) {
+    return dsm_fuse_initialize_map_inv(h, reference_frame_index, image, img_step, depth, depth_step, pose16, nullptr, local, n_local,
+                                       new_out, new_cap, n_new);
+}
+
+int dsm_fuse_initialize_map_inv(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
+                                const float *depth, size_t depth_step, const float *pose16, const float *inv_pose16,
+                                dsm_surfel *local, int32_t n_local, dsm_surfel *new_out, int32_t new_cap, int32_t *n_new) {
     if (!h) return DSM_E_INVALID;
     if (!pose16 || !n_new || (new_cap > 0 && !new_out) || new_cap < 0) return fail(h, DSM_E_INVALID, "null/negative argument");
     int rc = bind_device(h);
@@ -959,7 +1006,7 @@ int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint
     const int S = h->hc.n_seed;
     if ((rc = dropin_reserve(h, (size_t)(n_local > 0 ? n_local : 0) + (size_t)S))) return rc;
     if ((rc = dropin_frame(h, image, img_step, depth, depth_step))) return rc;
-    if ((rc = stage_params(h, 0, reference_frame_index, pose16))) return rc;
+    if ((rc = stage_params(h, 0, reference_frame_index, pose16, inv_pose16))) return rc;
     if ((rc = submit_part(h, false, false))) return rc;            // superpixels run while the host compares / copies the map
     if ((rc = dropin_map_in(h, local, n_local))) return rc;
     if ((rc = submit_part(h, false, true))) return rc;
@@ -980,6 +1027,12 @@ int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint
 int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step, const float *depth,
                  size_t depth_step, const float *pose16, dsm_surfel *local, int32_t *n_local, int32_t cap,
                  int32_t *n_new) {
+    return dsm_fuse_map_inv(h, reference_frame_index, image, img_step, depth, depth_step, pose16, nullptr, local, n_local, cap, n_new);
+}
+
+int dsm_fuse_map_inv(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step, const float *depth,
+                     size_t depth_step, const float *pose16, const float *inv_pose16, dsm_surfel *local, int32_t *n_local,
+                     int32_t cap, int32_t *n_new) {
     if (!h) return DSM_E_INVALID;
     if (!pose16 || !n_local || !n_new || cap < 0 || *n_local < 0 || *n_local > cap)
         return fail(h, DSM_E_INVALID, "null/negative argument");
@@ -991,7 +1044,7 @@ int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image,
     if (n_back > (size_t)h->hc.cap) n_back = (size_t)h->hc.cap;
     if ((rc = dropin_reserve(h, n_back > (size_t)n_in ? n_back : (size_t)n_in))) return rc;
     if ((rc = dropin_frame(h, image, img_step, depth, depth_step))) return rc;
-    if ((rc = stage_params(h, 0, reference_frame_index, pose16))) return rc;
+    if ((rc = stage_params(h, 0, reference_frame_index, pose16, inv_pose16))) return rc;
     if ((rc = submit_part(h, true, false))) return rc;             // superpixels run while the host compares / copies the map
     if ((rc = dropin_map_in(h, local, n_in))) return rc;
     if ((rc = submit_part(h, true, true))) return rc;
@@ -1284,13 +1337,60 @@ int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size
     return upload_frame(h, slot, image_dev, img_step, depth_dev, depth_step, hipMemcpyDeviceToDevice);
 }
 
+int dsm_frame_pitch(const dsm_handle *h, int32_t *pitch) {
+    if (!h || !pitch) return DSM_E_INVALID;
+    *pitch = h->hc.pitch;
+    return DSM_OK;
+}
+
+int dsm_frame_upload_async(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth, size_t depth_step) {
+    if (!h) return DSM_E_INVALID;
+    if (!image || !depth) return fail(h, DSM_E_INVALID, "null image/depth");
+    if (slot < 0 || slot >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slot, h->hc.n_slots);
+    const int w = h->hc.w, hh = h->hc.h, pitch = h->hc.pitch;
+    if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    hipStream_t up = device_upload_stream(h->device);
+    if (!up) return fail(h, DSM_E_HIP, "no upload stream on device %d", h->device);
+    if (!h->ev_up) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
+    // behind every frame enqueued so far for this handle (its map stream runs fuse + tail of every frame after the
+    // superpixel stages that read the slots, and waits for the batches the handle takes part in): they may read this slot
+    HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(up, h->ev_fence, 0));
+    uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot * h->hc.slot_elems;
+    float *dd = (float *)h->hc.depth_base + (int64_t)slot * h->hc.slot_elems;
+    // rows laid out with the slot's own pitch go up as ONE transfer per plane; any other step row by row (a 2-D copy is
+    // hundreds of small DMA transfers: correct, and several times slower)
+    if (img_step == (size_t)pitch) HIP_TRY(h, hipMemcpyAsync(di, image, (size_t)pitch * (size_t)(hh - 1) + (size_t)w, hipMemcpyHostToDevice, up));
+    else HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, hipMemcpyHostToDevice, up));
+    if (depth_step == (size_t)pitch * 4) HIP_TRY(h, hipMemcpyAsync(dd, depth, ((size_t)pitch * (size_t)(hh - 1) + (size_t)w) * 4, hipMemcpyHostToDevice, up));
+    else HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, hipMemcpyHostToDevice, up));
+    HIP_TRY(h, hipEventRecord(h->ev_up, up));
+    h->up_pending = ~0ull;
+    return DSM_OK;
+}
+
+int dsm_frame_uploads_wait(dsm_handle *h) {
+    if (!h) return DSM_E_INVALID;
+    if (!h->ev_up) return DSM_OK;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventSynchronize(h->ev_up));
+    return DSM_OK;
+}
+
 int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, const float *pose16) {
+    return dsm_fuse_frame_resident_inv(h, slot, reference_frame_index, pose16, nullptr);
+}
+
+int dsm_fuse_frame_resident_inv(dsm_handle *h, int slot, int reference_frame_index, const float *pose16, const float *inv_pose16) {
     if (!h) return DSM_E_INVALID;
     if (!pose16) return fail(h, DSM_E_INVALID, "null pose");
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
     int rc = bind_device(h);
     if (rc) return rc;
-    if ((rc = stage_params(h, slot, reference_frame_index, pose16))) return rc;
+    if ((rc = stage_params(h, slot, reference_frame_index, pose16, inv_pose16))) return rc;
     if ((rc = submit_frame(h, true))) return rc;
     if (!h->own_up_stream) return DSM_OK;
     // live path: the next upload into this slot waits for exactly this frame
@@ -1301,6 +1401,11 @@ int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, 
 }
 
 int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
+    return dsm_replay_enqueue_inv(h, n, slots, ref_idx, poses16, nullptr);
+}
+
+int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
+                           const float *inv_poses16) {
     if (!h) return DSM_E_INVALID;
     if (n < 0 || (n > 0 && (!slots || !ref_idx || !poses16))) return fail(h, DSM_E_INVALID, "null/negative argument");
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
@@ -1308,7 +1413,8 @@ int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int
     if (rc) return rc;
     for (int i = 0; i < n;) {
         int m = 0;
-        if ((rc = stage_params_batch(h, n - i, slots + i, ref_idx + i, poses16 + 16 * (size_t)i, &m))) return rc;
+        if ((rc = stage_params_batch(h, n - i, slots + i, ref_idx + i, poses16 + 16 * (size_t)i,
+                                     inv_poses16 ? inv_poses16 + 16 * (size_t)i : nullptr, &m))) return rc;
         for (int j = 0; j < m;) {
             const int G = group_size(h);
             if (group_path(h) && m - j >= G && h->frames_submitted % G == 0) {
@@ -1392,6 +1498,15 @@ int dsm_debug_set_label_buffer(dsm_handle *h, int which, const int32_t *in) {
     if (!h || !in || which < 0 || which > 1) return DSM_E_INVALID;
     int rc = bind_device(h);
     if (rc) return rc;
+    // the kernels index per-seed arrays with the labels they read (tmin[label], core[label]): an injected image must hold
+    // seed indices, and -1 exactly where the assignment stage itself writes it (pixels beyond every cell's reach)
+    for (int y = 0; y < h->hc.h; y++)
+        for (int x = 0; x < h->hc.w; x++) {
+            const int32_t l = in[(size_t)y * h->hc.w + x];
+            const bool reach = has_candidate_cell(x, y, h->hc.gw, h->hc.gh);
+            if (l >= h->hc.n_seed || l < -1 || (l == -1) == reach)
+                return fail(h, DSM_E_INVALID, "label %d at (%d, %d) is not a superpixel index of this %d-seed grid", l, x, y, h->hc.n_seed);
+        }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy2D(which ? h->hc.label_alt : h->hc.label, (size_t)h->hc.pitch * 4, in, (size_t)h->hc.w * 4,
                            (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyHostToDevice));
@@ -1435,6 +1550,7 @@ int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap) {
     if (!h) return DSM_E_INVALID;
     if (cap < 0 || cap > kFitSmallCap) return fail(h, DSM_E_INVALID, "fit_small_cap %d out of range [0, %d]", cap, kFitSmallCap);
     if (h->frames_submitted != 0) return fail(h, DSM_E_STATE, "dsm_debug_set_fit_small_cap: the handle has already fused frames");
+    if (h->batches_joined != 0) return fail(h, DSM_E_STATE, "dsm_debug_set_fit_small_cap: the handle has already joined a batch (which holds a copy of its context)");
     int rc = bind_device(h);
     if (rc) return rc;
     for (int p = 0; p < h->n_pipe; p++) h->pipe[p].ctx.fit_small_cap = cap;
@@ -1473,20 +1589,40 @@ struct BatchStreamPool {
     hipStream_t st[64][kBatchStreams] = {};
     bool made[64] = {};
     int next[64] = {};
+    hipStream_t up[64] = {}; // asynchronous frame uploads, created at the first dsm_frame_upload_async on the device
 } g_batch_streams;
 
-void batch_streams_reserve(int device) {
-    if (device < 0 || device >= 64) return;
+// (The reserved streams live as long as the process, like the HIP context they belong to: a static destructor would run
+// after the runtime's own teardown.)
+hipError_t batch_streams_reserve(int device) {
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
-    if (g_batch_streams.made[device]) return;
+    if (g_batch_streams.made[device]) return hipSuccess;
+    for (int i = 0; i < kBatchStreams; i++) {
+        const hipError_t e = hipStreamCreateWithFlags(&g_batch_streams.st[device][i], hipStreamNonBlocking);
+        if (e != hipSuccess) { // all or nothing: the next dsm_create tries again
+            for (int j = 0; j < i; j++) { (void)hipStreamDestroy(g_batch_streams.st[device][j]); g_batch_streams.st[device][j] = nullptr; }
+            g_batch_streams.st[device][i] = nullptr;
+            return e;
+        }
+    }
     g_batch_streams.made[device] = true;
-    for (int i = 0; i < kBatchStreams; i++)
-        if (hipStreamCreateWithFlags(&g_batch_streams.st[device][i], hipStreamNonBlocking) != hipSuccess) g_batch_streams.st[device][i] = nullptr;
+    return hipSuccess;
 }
 hipStream_t batch_stream_at(int device, int i) {
     if (device < 0 || device >= 64 || i < 0 || i >= kBatchStreams) return nullptr;
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
     return g_batch_streams.made[device] ? g_batch_streams.st[device][i] : nullptr;
+}
+// ONE upload stream per device, shared by its handles (a stream per handle would spread the handles' own streams
+// unevenly over the hardware queues, see DSM_FLAG_UPLOAD_STREAM in dsm.h): the copies are DMA transfers ordered by events,
+// they need no queue of their own per subsequence.
+hipStream_t device_upload_stream(int device) {
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_batch_streams.mu);
+    if (!g_batch_streams.up[device] && hipStreamCreateWithFlags(&g_batch_streams.up[device], hipStreamNonBlocking) != hipSuccess)
+        g_batch_streams.up[device] = nullptr;
+    return g_batch_streams.up[device];
 }
 hipStream_t batch_stream_take(int device) {
     if (device < 0 || device >= 64) return nullptr;
@@ -1542,17 +1678,22 @@ int batch_rings_in_step(dsm_batch *b) {
 }
 
 // params of frames [i0, i0+m) of every handle go up on the handles' own streams; the batch stream waits for them
-int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
+int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
+                const float *inv_poses16 = nullptr) {
     for (size_t j = 0; j < b->hs.size(); j++) {
         dsm_handle *h = b->hs[j];
         if (!h->map_valid) return bfail(b, DSM_E_STATE, "handle %zu has no resident map: call dsm_map_upload first (n may be 0)", j);
         const size_t o = j * (size_t)n_frames + (size_t)i0;
         int staged = 0;
-        const int rc = stage_params_batch(h, m, slots + o, ref_idx + o, poses16 + 16 * o, &staged);
+        const int rc = stage_params_batch(h, m, slots + o, ref_idx + o, poses16 + 16 * o, inv_poses16 ? inv_poses16 + 16 * o : nullptr, &staged);
         if (rc) return bfail(b, rc, "handle %zu: %s", j, h->err.c_str());
         if (staged != m) return bfail(b, DSM_E_STATE, "handle %zu: parameter rings of the batch are out of step", j);
         BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
         BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
+        if (h->up_pending & kBatchBit) { // frames this handle was sent with dsm_frame_upload_async
+            BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_up, 0));
+            h->up_pending &= ~kBatchBit;
+        }
     }
     return DSM_OK;
 }
@@ -1605,6 +1746,7 @@ int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
     dsm_batch *b = new (std::nothrow) dsm_batch();
     if (!b) return bfail(nullptr, DSM_E_HIP, "out of host memory");
     b->hs.assign(handles, handles + n);
+    for (dsm_handle *h : b->hs) h->batches_joined++;
     b->device = handles[0]->device;
     auto bail = [&](int code) {
         g_batch_create_error = b->err;
@@ -1654,6 +1796,11 @@ void dsm_batch_destroy(dsm_batch *b) {
 }
 
 int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx, const float *poses16) {
+    return dsm_batch_replay_enqueue_inv(b, n_frames, slots, ref_idx, poses16, nullptr);
+}
+
+int dsm_batch_replay_enqueue_inv(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
+                                 const float *inv_poses16) {
     if (!b) return DSM_E_INVALID;
     if (n_frames < 0 || (n_frames > 0 && (!slots || !ref_idx || !poses16))) return bfail(b, DSM_E_INVALID, "null/negative argument");
     BHIP_TRY(b, hipSetDevice(b->device));
@@ -1664,19 +1811,14 @@ int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slot
         const int ring = (int)(h0->frames_submitted % kParamRing);
         if (m > kParamRing - ring) m = kParamRing - ring;
         if (m > kParamRing / 2) m = kParamRing / 2;
-        int rc = batch_stage(b, n_frames, i, m, slots, ref_idx, poses16);
+        int rc = batch_stage(b, n_frames, i, m, slots, ref_idx, poses16, inv_poses16);
         if (rc) return rc;
         if ((rc = batch_map_grows(b, m))) return rc;
         if (!b->graph) {
-            hipGraph_t g = nullptr;
-            BHIP_TRY(b, hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-            const hipError_t le = launch_frame(h0->pipe[0].ctx, b->cap_max, b->tail_large ? b->cap_max : 0, true, b->stream, nullptr, 0, kNumStages - 1, b->d_ctxs, (int)b->hs.size());
-            const hipError_t ce = hipStreamEndCapture(b->stream, &g);
-            if (le != hipSuccess) return bfail(b, DSM_E_HIP, "kernel launch during capture: %s", hipGetErrorString(le));
-            if (ce != hipSuccess) return bfail(b, DSM_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-            const hipError_t ie = hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0);
-            hipGraphDestroy(g);
-            if (ie != hipSuccess) return bfail(b, DSM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+            const std::string err = capture_graph([&](hipStream_t st) {
+                return launch_frame(h0->pipe[0].ctx, b->cap_max, b->tail_large ? b->cap_max : 0, true, st, nullptr, 0, kNumStages - 1, b->d_ctxs, (int)b->hs.size());
+            }, &b->graph);
+            if (!err.empty()) return bfail(b, DSM_E_HIP, "%s", err.c_str());
         }
         for (int f = 0; f < m; f++) BHIP_TRY(b, hipGraphLaunch(b->graph, b->stream));
         if ((rc = batch_advance(b, m))) return rc;

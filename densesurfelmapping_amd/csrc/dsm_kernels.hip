@@ -201,6 +201,11 @@ template <typename T> __device__ __forceinline__ T ld_off(const T *base, unsigne
 template <typename T> __device__ __forceinline__ void st_off(T *base, unsigned byte_off, T v) {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+template <typename T> __device__ __forceinline__ T ld_vec(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ int comp(const int4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+__device__ __forceinline__ float comp(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 // grid cell of seed s (s < 65 536: dsm_create): the quotient by multiplication with the reciprocal the host rounded up
 __device__ __forceinline__ void seed_cell(const DeviceCtx *c, int s, int &gx, int &gy) {
     gy = c->gw > 1 ? (int)__umulhi((unsigned)s, c->gw_magic) : s;
@@ -569,9 +574,8 @@ __device__ __forceinline__ float huber_passes_wave(const float *dl, float *lt, i
 // so member depths are compacted in order into LDS and summed sequentially.
 constexpr int kWin = 2 * kCell; // 16
 
-// APPLY (sweeps >= 1): the label image of this sweep is  new(p) = T[old(p)] < p ? pick(p) : old(p)  (see
-// k_assign); it is formed on the fly for the window, and every wave stores it for the pixels of its
-// own cell (ragged right/bottom pixels go to the last cell column/row) into the other label buffer.
+// The label image of a sweep >= 1 is  new(p) = T[old(p)] < p ? pick(p) : old(p)  (see k_assign): k_apply_labels forms it,
+// once per pixel, before the seeds are updated; the label buffers take turns (sweep_labels).
 // Second half of update_seeds for one seed (one wave): the sums of its members are in the lanes' registers, the
 // member depths > 0.1 in window row-major order in dl[0..nd).
 __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__ c, int sweep, int s, int lane, int wx0, int wy0,
@@ -614,28 +618,31 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
     }
 }
 
+// the buffer that holds the label image while the seeds of `sweep` are updated: sweep 0 writes `label` (k_assign), every
+// later sweep is applied from the previous sweep's buffer into the other one; after the last sweep (2) the image is in `label`
+__device__ __forceinline__ int32_t *sweep_labels(const DeviceCtx *c, int sweep) { return (sweep & 1) ? c->label_alt : c->label; }
+
 // update_seeds for ONE seed by one whole wave (lanes cover the 16x16 window, 4 pixels each): the form every seed took
-// until round 3.  Today it serves the seeds whose depth list outgrows the lane-per-seed kernel's LDS rows (below).
-// s is wave-uniform; dl / lt are two lists of 256 floats in LDS owned by this wave.  STORE: also write the sweep's new
-// labels of the seed's own cell.
-template <bool APPLY, bool STORE>
+// until round 3.  Today it serves launches for one handle or a few, and the seeds whose depth list outgrows the
+// lane-per-seed kernel's longest LDS rows (below).  s is wave-uniform; dl / lt are two lists of 256 floats in LDS owned
+// by this wave.
 __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c, int sweep, int s, float *dl, float *lt) {
     const int lane = lane_id();
     stamp(c, sweep, s, 0, lane);
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
-    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
+    const int32_t *lbl = sweep_labels(c, sweep);
     const int w = c->w, h = c->h, pitch = c->pitch;
     int gx, gy;
     seed_cell(c, s, gx, gy);
     const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
     const int t_self = c->tmin[s];
+    if (t_self == kIntMax) return; // stable: FF.cpp:479-480
     const float4 old = c->core[s]; // needed only after the sums: issued with the window loads, not behind them
     stamp(c, sweep, s, 1, lane);
     int cnt = 0, sdx = 0, sdy = 0, si = 0, nd = 0;
-    int lab[4], pi[4], cd[4], pk[4];
+    int lab[4], pi[4];
     float pd[4];
     bool pimg[4];
     // pixel key of this lane's first window pixel; the other three are 4, 8, 12 rows further down (keys are
@@ -647,27 +654,12 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
     for (int k = 0; k < 4; k++) { // independent loads, one round trip
         const int y = y0 + 4 * k;
         pimg[k] = x_in && y >= 0 && y < h;
-        pk[k] = pimg[k] ? key0 + k * row4 : 0;
-        const unsigned o4 = (unsigned)pk[k] << 2;
-        lab[k] = ld_off(label_in, o4);
-        if (APPLY) cd[k] = ld_off(c->cand, o4);
+        const int pk = pimg[k] ? key0 + k * row4 : 0;
+        const unsigned o4 = (unsigned)pk << 2;
+        lab[k] = ld_off(lbl, o4);
         pd[k] = ld_off(dep, o4);
-        pi[k] = (int)ld_off(img, (unsigned)pk[k]);
+        pi[k] = (int)ld_off(img, (unsigned)pk);
     }
-    if (APPLY) {
-        int tl[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) tl[k] = ld_off(c->tmin, (unsigned)lab[k] << 2);
-        const bool own_x = ((x >> 3) < c->gw ? (x >> 3) : c->gw - 1) == gx;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int y = y0 + 4 * k;
-            if (tl[k] < pk[k]) lab[k] = cd[k];
-            const int oy = (y >> 3) < c->gh ? (y >> 3) : c->gh - 1;
-            if (STORE && pimg[k] && own_x && oy == gy) st_off(label_out, (unsigned)pk[k] << 2, lab[k]);
-        }
-    }
-    if (t_self == kIntMax) return; // stable: FF.cpp:479-480
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int idx = k * 64 + lane;
@@ -684,6 +676,32 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
         nd += __popcll(m);
     }
     update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
+}
+
+// ---- the label image of a sweep >= 1, one thread per four pixels of a row:  new(p) = T[old(p)] < p ? pick(p) : old(p)
+// with T = tmin after k_resolve (see k_assign).  Until round 4 every seed's window walk formed it on the fly for the 256
+// pixels of its window -- every pixel four times over, each time behind a gather of tmin[old label] by 64 lanes that
+// hold 64 different seeds -- and the registers of that (two more row planes, the gathered tmin) held the lane-per-seed
+// kernel to one wave per SIMD.  Here a pixel is resolved once, and neighbouring pixels mostly share their old label: a
+// wave's gather touches a handful of lines.  Pixels beyond every cell's reach keep their -1 (no seed, no tmin).
+template <bool BATCH> __global__ __launch_bounds__(256) void k_apply_labels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    const BlockOf blk = block_of<BATCH>();
+    DeviceCtx batch_ctx;
+    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
+    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    const int pitch = c->pitch;
+    const int xq = blk.x * 64 + (threadIdx.x & 63), y = blk.y * 4 + (threadIdx.x >> 6);
+    if (4 * xq >= pitch || y >= c->h) return;
+    const int key0 = __mul24(y, pitch) + 4 * xq;
+    const unsigned o4 = (unsigned)key0 << 2;
+    const int4 lab = ld_vec<int4>(sweep_labels(c, sweep - 1), o4), cd = ld_vec<int4>(c->cand, o4);
+    const int l[4] = {lab.x, lab.y, lab.z, lab.w}, pk[4] = {cd.x, cd.y, cd.z, cd.w};
+    int t[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[j] = l[j] >= 0 ? ld_off(c->tmin, (unsigned)l[j] << 2) : kIntMax;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = t[j] < key0 + j ? pk[j] : l[j];
+    *reinterpret_cast<int4 *>(reinterpret_cast<char *>(sweep_labels(c, sweep)) + o4) = make_int4(o[0], o[1], o[2], o[3]);
 }
 
 // One Huber-Newton pass (FF.cpp:536-553) of up to 64 seeds at once, one chain per lane: a = ordered sum of 2*r over the
@@ -750,50 +768,55 @@ __device__ __forceinline__ float huber_pass_regs(const float (&v)[kRestRegs], in
 }
 
 // ---- update_seeds, ONE LANE PER SEED: a wave takes 64 consecutive seeds (launches batched over handles).
-// The wave-per-seed form above spends most of its instructions on work one lane could do: window addressing, the label
-// apply, the ballot / rank compaction and two wave reductions are repeated by every wave for every window, and the
-// ordered sums of a Huber-Newton pass are serial chains of adds executed by all 64 lanes (546 VALU wave-instructions
-// per seed, profiles/r02_pmc_sq_batch8.md) -- and batched launches are bound by VALU issue, not by bytes.  Here every
-// lane walks its own seed's 16x16 window in row-major order (16-byte loads, rows fetched three ahead), keeps the integer
-// sums and the ordered depth sum in registers, compacts its member depths in order into its own LDS row ([element][lane]:
+// The wave-per-seed form above spends most of its instructions on work one lane could do: window addressing, the
+// ballot / rank compaction and two wave reductions are repeated by every wave for every window, and the ordered sums of
+// a Huber-Newton pass are serial chains of adds executed by all 64 lanes (546 VALU wave-instructions per seed,
+// profiles/r02_pmc_sq_batch8.md) -- and batched launches are bound by VALU issue, not by bytes.  Here every lane walks
+// its own seed's 16x16 window in row-major order (16-byte loads, rows fetched three ahead), keeps the integer sums and the
+// ordered depth sum in registers, compacts its member depths in order into its own LDS row ([element][lane]:
 // conflict-free whatever the lanes' list lengths), and runs the first Huber-Newton pass as 64 independent chains: one
-// v_add serves 64 seeds.  Same operations on the same operands in the same order as the reference, seed by seed.
-//
-// What the first pass does not finish goes to k_update_seeds_rest through two queues: the 13 % of the seeds that need
-// more passes, packed 64 to a wave again, and the seeds whose list does not fit an LDS row of kLaneCap depths (a
+// v_add serves 64 seeds.  Same operations on the same operands in the same order as the reference, seed by seed.  The
+// label image it reads is the sweep's own (k_apply_labels): 193 registers, two waves per SIMD where the form that
+// applied the labels inside the walk (round 3: two more row planes, a gathered tmin per pixel) held one.
+// What the first Huber pass does not finish goes to k_update_seeds_rest through two queues: the 13 % of the seeds that
+// need more passes, packed 64 to a wave again, and the seeds whose list does not fit an LDS row of kLaneCap depths (a
 // superpixel averages 53, the longest of 64 neighbours ~95; 0.05 % of all seeds have more than 127), which get a wave
 // of their own.  Same arithmetic on every path, so which one a seed takes changes nothing in its result.
+// (Round 4 measured the occupancy lever of VERDICT r03 in this form: rows of 79 depths -- 20 KB, eight waves per CU
+// instead of five -- with a second lane-per-seed pass over the 10 % longer lists, long rows, seeds taken from a queue:
+// bit-exact, and slower in every configuration on one box, 26.5 k against 28.8-30.6 k frames/s for 32 subsequences in 4
+// batches, 30.5 k against 31.7 k for 128: the second pass is a full window walk again and sits between two launches
+// that wait for it.  tools/_exp/r04_update_twotier.patch.)
 constexpr int kLaneCap = kRestListCap; // + the spare row: 32 KB per wave, five waves per CU
+// rest_count[2 * sweep + ...] (zeroed by k_init_seeds) / where the queues live in `worklist` (free between k_resolve and
+// the next k_assign): entries of seeds that need more Huber passes (int4, from 0) | seeds queued for a wave of their own
+enum { kQueueRest = 0, kQueueWave = 1 };
+__device__ __forceinline__ int32_t *queue_wave(const DeviceCtx *c) { return c->worklist + 4 * c->n_seed; }
 
-struct LaneRow { // one window row of one lane: 16 labels, picks, depths, intensities
-    int4 lab[4], cd[4];
+struct LaneRow { // one window row of one lane: 16 labels, depths, intensities
+    int4 lab[4];
     float4 dp[4];
     unsigned im[4];
 };
-template <typename T> __device__ __forceinline__ T ld_vec(const void *base, unsigned byte_off) {
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-__device__ __forceinline__ int comp(const int4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
-__device__ __forceinline__ float comp(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 
-template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+    constexpr int CAP = kLaneCap;
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    __shared__ __attribute__((aligned(16))) float s_list[(kLaneCap + 1) * 64]; // [element][lane] + one spare row
+    __shared__ __attribute__((aligned(16))) float s_list[(CAP + 1) * 64]; // [element][lane] + one spare row
     const int lane = lane_id();
     const int S = c->n_seed;
+    const FrameParams &fp = frame_params(c);
+    const uint8_t *img = frame_image(c, fp);
+    const float *dep = frame_depth(c, fp);
+    const int32_t *lbl = sweep_labels(c, sweep);
+    const int w = c->w, h = c->h, pitch = c->pitch;
     // bottom rows first, see seed_of_block
     const int s = (((S + 63) >> 6) - 1 - blk.x) * 64 + lane;
     const bool live = s < S;
     const int sc = live ? s : S - 1;
-    const FrameParams &fp = frame_params(c);
-    const uint8_t *img = frame_image(c, fp);
-    const float *dep = frame_depth(c, fp);
-    const int32_t *label_in = (APPLY && ((sweep - 1) & 1)) ? c->label_alt : c->label;
-    int32_t *label_out = (sweep & 1) ? c->label_alt : c->label;
-    const int w = c->w, h = c->h, pitch = c->pitch;
     int gx, gy;
     seed_cell(c, sc, gx, gy);
     const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
@@ -813,7 +836,6 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     bool col_stat[kWin];
 #pragma unroll
     for (int j = 0; j < kWin; j++) col_stat[j] = (unsigned)(wx0 + j) < (unsigned)(w - 1);
-    const bool last_col_cell = gx == c->gw - 1, last_row_cell = gy == c->gh - 1;
 
     auto load_row = [&](int r) {
         LaneRow R;
@@ -823,19 +845,11 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const unsigned o = row + (unsigned)qx[q], o4 = o << 2;
-            R.lab[q] = ld_vec<int4>(label_in, o4);
-            if (APPLY) R.cd[q] = ld_vec<int4>(c->cand, o4);
+            R.lab[q] = ld_vec<int4>(lbl, o4);
             R.dp[q] = ld_vec<float4>(dep, o4);
             R.im[q] = ld_vec<unsigned>(img, o);
         }
         return R;
-    };
-    struct Tmins { int t[kWin]; };
-    auto gather_tmin = [&](const LaneRow &R) {
-        Tmins T;
-#pragma unroll
-        for (int j = 0; j < kWin; j++) T.t[j] = APPLY ? ld_off(c->tmin, (unsigned)comp(R.lab[j >> 2], j & 3) << 2) : 0;
-        return T;
     };
 
     int acc_ci = 0;  // member count << 16 | intensity sum  (<= 225 members, 225 * 255 < 2^16)
@@ -845,42 +859,20 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     int acc_y = 0, cnt_prev = 0; // sum of the members' window rows, from the member count of every row
     // member depths > 0.1 in window row-major order: element i of this lane at s_list[i * 64 + lane]; `tail` = byte address
     // of the list's end
-    const unsigned lane4 = (unsigned)lane << 2, tail_cap = ((unsigned)kLaneCap << 8) + lane4;
+    const unsigned lane4 = (unsigned)lane << 2, tail_cap = ((unsigned)CAP << 8) + lane4;
     unsigned tail = lane4;
     float sum = 0.0f; // their sequential fp32 sum, FF.cpp:511
 
-    // one window row of every lane's seed: apply + own-cell labels, membership, sums, depth list
-    auto process_row = [&](const LaneRow &A, const Tmins &T, int r) {
+    // one window row of every lane's seed: membership, sums, depth list
+    auto process_row = [&](const LaneRow &A, int r) {
         const int y = wy0 + r;
-        const int key0 = __mul24(y, pitch) + wx0; // pixel key of the row's first window pixel (compared only where the pixel is real)
-        int lab[kWin];
-#pragma unroll
-        for (int j = 0; j < kWin; j++) {
-            lab[j] = comp(A.lab[j >> 2], j & 3);
-            if (APPLY && T.t[j] < key0 + j) lab[j] = comp(A.cd[j >> 2], j & 3); // new(p) = T[old(p)] < p ? pick(p) : old(p)
-        }
-        if (APPLY) {
-            // the sweep's new labels of this seed's own cell (window rows / columns 4..11; ragged right / bottom pixels
-            // belong to the last cell column / row)
-            const bool own_row = (r >= kCell / 2 && r < kCell / 2 + kCell) || (r >= kCell / 2 + kCell && last_row_cell && y < h);
-            if (live && own_row) {
-                const unsigned o4 = (unsigned)(__mul24(y, pitch) + wx0 + kCell / 2) << 2; // byte offset of window column 4 (>= 0)
-                *reinterpret_cast<int4 *>(reinterpret_cast<char *>(label_out) + o4) = make_int4(lab[4], lab[5], lab[6], lab[7]);
-                *reinterpret_cast<int4 *>(reinterpret_cast<char *>(label_out) + (o4 + 16u)) = make_int4(lab[8], lab[9], lab[10], lab[11]);
-                if (last_col_cell) {
-#pragma unroll
-                    for (int j = 12; j < kWin; j++)
-                        if (wx0 + j < w) st_off(label_out, o4 + 4u * (j - kCell / 2), lab[j]);
-                }
-            }
-        }
         const int s_row = (unsigned)y < (unsigned)(h - 1) ? s_match : -2;
         // branch-free: every lane is a different seed, so a branch here only adds exec-mask bookkeeping.  The depth is
         // stored at the list's end unconditionally and the end advances only past a member depth > 0.1 (a later store
-        // overwrites a rejected one; elements from kLaneCap on collapse into the spare row kLaneCap).
+        // overwrites a rejected one; elements from CAP on collapse into the spare row CAP).
 #pragma unroll
         for (int j = 0; j < kWin; j++) {
-            const bool mem = lab[j] == s_row && col_stat[j];
+            const bool mem = comp(A.lab[j >> 2], j & 3) == s_row && col_stat[j];
             const int pi = (int)((A.im[j >> 2] >> (8 * (j & 3))) & 0xffu);
             acc_ci += mem ? pi | 0x10000 : 0;
             colcnt[j] += mem ? 1 : 0;
@@ -901,29 +893,25 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
         cnt_prev = cnt_now;
     };
 
-    // Four row buffers in rotation: a row's loads are issued three rows before it is worked on, the tmin gather of its
-    // (old) labels one row before.  The loop is NOT unrolled further: every wave runs this code once per four rows, and a
-    // fully unrolled window (50 KB of straight-line code) is paced by instruction fetch, not by the SIMD --
-    // measured 82 us per launch against 20 us for the wave-per-seed kernel it replaces.
+    // Four row buffers in rotation: a row's loads are issued three rows before it is worked on.  The loop is NOT unrolled
+    // further: every wave runs this code once per four rows, and a fully unrolled window (50 KB of straight-line code) is
+    // paced by instruction fetch, not by the SIMD -- measured 82 us per launch against 20 us for the wave-per-seed kernel
+    // it replaces.
     LaneRow B0 = load_row(0), B1 = load_row(1), B2 = load_row(2), B3;
-    Tmins T0 = gather_tmin(B0), T1;
 #pragma unroll 1
     for (int r = 0; r < kWin; r += 4) {
         B3 = load_row(r + 3);
-        T1 = gather_tmin(B1);
         __builtin_amdgcn_sched_barrier(0);
-        process_row(B0, T0, r);
+        process_row(B0, r);
         if (r + 4 < kWin) B0 = load_row(r + 4);
-        T0 = gather_tmin(B2);
         __builtin_amdgcn_sched_barrier(0);
-        process_row(B1, T1, r + 1);
+        process_row(B1, r + 1);
         if (r + 4 < kWin) B1 = load_row(r + 5);
-        T1 = gather_tmin(B3);
         __builtin_amdgcn_sched_barrier(0);
-        process_row(B2, T0, r + 2);
-        if (r + 4 < kWin) { B2 = load_row(r + 6); T0 = gather_tmin(B0); }
+        process_row(B2, r + 2);
+        if (r + 4 < kWin) B2 = load_row(r + 6);
         __builtin_amdgcn_sched_barrier(0);
-        process_row(B3, T1, r + 3);
+        process_row(B3, r + 3);
     }
 
     // ---- per-lane finish: means, stability, robust mean depth (FF.cpp:514-556)
@@ -931,7 +919,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     const int nd = (int)((tail - lane4) >> 8);
     const bool empty = stats && cnt == 0;
     if (empty) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(S, s)], s); // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
-    const bool over = stats && nd > kLaneCap;
+    const bool over = stats && nd > CAP;
     const bool fin = stats && cnt > 0 && !over;
     int acc_x = 0;
 #pragma unroll
@@ -949,7 +937,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     // ---- the FIRST Huber-Newton pass of all 64 seeds, one chain per lane.  87 % of all seeds are done after it
     // (|delta| < 0.01: FF.cpp:554).
     if (__ballot(run) != 0) {
-        const float delta = huber_pass_lanes([&](int i) { return s_list[(i < kLaneCap ? i : kLaneCap) * 64 + lane]; }, run ? nd : 0, md, hr);
+        const float delta = huber_pass_lanes([&](int i) { return s_list[(i < CAP ? i : CAP) * 64 + lane]; }, run ? nd : 0, md, hr);
         if (run) md = md + delta;
         if (fabsf(delta) < flt_above(0.01)) run = false; // (double)delta < 0.01 && (double)delta > -0.01
     }
@@ -962,12 +950,12 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     if (rm | om) {
         int base_r = 0, base_o = 0;
         if (lane == 0) {
-            if (rm) base_r = atomicAdd(&c->rest_count[2 * sweep], __popcll(rm));
-            if (om) base_o = atomicAdd(&c->rest_count[2 * sweep + 1], __popcll(om));
+            if (rm) base_r = atomicAdd(&c->rest_count[2 * sweep + kQueueRest], __popcll(rm));
+            if (om) base_o = atomicAdd(&c->rest_count[2 * sweep + kQueueWave], __popcll(om));
         }
         base_r = __builtin_amdgcn_readfirstlane(base_r);
         base_o = __builtin_amdgcn_readfirstlane(base_o);
-        if (over) c->worklist[4 * S + base_o + rank_below(om)] = s; // (worklist: free between k_resolve and the next k_assign)
+        if (over) queue_wave(c)[base_o + rank_below(om)] = s;
         const int q = base_r + rank_below(rm);
         if (run) reinterpret_cast<int4 *>(c->worklist)[q] = make_int4(s, nd, __float_as_int(md), 0);
         const unsigned dst0 = (((unsigned)(q >> 6) * kLaneCap) << 8) + ((unsigned)(q & 63) << 2);
@@ -990,7 +978,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
 // scratch by one wave each.
 constexpr int kRestOverBlocks = 32;
 constexpr int kLaneBatch = 8; // handles per launch from which the lane-per-seed kernels are used (launch_frame)
-template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds_rest(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds_rest(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
@@ -999,14 +987,14 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
     const int lane = lane_id();
     const int S = c->n_seed, n_dense = (S + 63) >> 6;
     if (blk.x >= n_dense) {
-        const int n_over = c->rest_count[2 * sweep + 1];
+        const int n_over = c->rest_count[2 * sweep + kQueueWave];
         for (int e = blk.x - n_dense; e < n_over; e += kRestOverBlocks) {
-            update_seed_wave<APPLY, false>(c, sweep, __builtin_amdgcn_readfirstlane(c->worklist[4 * S + e]), s_depth, s_term);
+            update_seed_wave(c, sweep, __builtin_amdgcn_readfirstlane(queue_wave(c)[e]), s_depth, s_term);
             wave_lds_sync();
         }
         return;
     }
-    const int n = c->rest_count[2 * sweep];
+    const int n = c->rest_count[2 * sweep + kQueueRest];
     if (blk.x * 64 >= n) return;
     const int q = blk.x * 64 + lane;
     const bool live = q < n;
@@ -1046,7 +1034,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(64) void k_update
 // latency -- it ends with its slowest wave (~20 us), the lane-per-seed pair above with the slowest of its two stages each
 // (~45 us) -- and not the instructions issued, which is what bounds launches batched over many handles (kLaneBatch).
 // Same results, bit for bit.
-template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds_wave(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
+template <bool BATCH> __global__ __launch_bounds__(256) void k_update_seeds_wave(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
@@ -1057,7 +1045,7 @@ template <bool APPLY, bool BATCH> __global__ __launch_bounds__(256) void k_updat
     // (one seed per wave: the index lives in a scalar register, and so does every address formed from it)
     const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh));
     if (s < 0) return;
-    update_seed_wave<APPLY, true>(c, sweep, s, s_depth[wv], s_term[wv]);
+    update_seed_wave(c, sweep, s, s_depth[wv], s_term[wv]);
 }
 
 // Seeds at or after the first pixel-less unstable seed of their worker chunk keep their old state.
@@ -2646,6 +2634,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
     const dim3 g_tile1((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<1>::kH - 1) / AssignTile<1>::kH);
     const dim3 g_tile4((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<4>::kH - 1) / AssignTile<4>::kH);
     const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
+    const dim3 g_quad4((hc.pitch / 4 + 63) / 64, (hc.h + 3) / 4); // thread per four pixels of a row, 256 x 4 per block
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
     if (lanes) hipLaunchStage(k_init_seeds_lanes<true>, k_init_seeds_lanes<true>, g_seed_thr, dim3(256));
@@ -2656,27 +2645,21 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
             if (lanes) hipLaunchStage((k_assign<true, true, 4>), (k_assign<true, true, 4>), g_tile4, dim3(256), sweep);
             else hipLaunchStage((k_assign<true, false, 1>), (k_assign<true, true, 1>), g_tile1, dim3(256), sweep);
             DSM_MARK();
-            if (lanes) {
-                hipLaunchStage((k_update_seeds<false, true>), (k_update_seeds<false, true>), g_seed_lane, dim3(64), sweep);
-                hipLaunchStage((k_update_seeds_rest<false, true>), (k_update_seeds_rest<false, true>), g_seed_rest, dim3(64), sweep);
-            } else {
-                hipLaunchStage((k_update_seeds_wave<false, false>), (k_update_seeds_wave<false, true>), g_seed_wave, dim3(256), sweep);
-            }
-            DSM_MARK();
         } else {
             if (lanes) hipLaunchStage((k_assign<false, true, 4>), (k_assign<false, true, 4>), g_tile4, dim3(256), sweep);
             else hipLaunchStage((k_assign<false, false, 1>), (k_assign<false, true, 1>), g_tile1, dim3(256), sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
-            DSM_MARK();
-            if (lanes) {
-                hipLaunchStage((k_update_seeds<true, true>), (k_update_seeds<true, true>), g_seed_lane, dim3(64), sweep);
-                hipLaunchStage((k_update_seeds_rest<true, true>), (k_update_seeds_rest<true, true>), g_seed_rest, dim3(64), sweep);
-            } else {
-                hipLaunchStage((k_update_seeds_wave<true, false>), (k_update_seeds_wave<true, true>), g_seed_wave, dim3(256), sweep);
-            }
+            hipLaunchStage(k_apply_labels<false>, k_apply_labels<true>, g_quad4, dim3(256), sweep); // (part of the resolve stage: the sweep's label image)
             DSM_MARK();
         }
+        if (lanes) {
+            hipLaunchStage(k_update_seeds<true>, k_update_seeds<true>, g_seed_lane, dim3(64), sweep);
+            hipLaunchStage(k_update_seeds_rest<true>, k_update_seeds_rest<true>, g_seed_rest, dim3(64), sweep);
+        } else {
+            hipLaunchStage(k_update_seeds_wave<false>, k_update_seeds_wave<true>, g_seed_wave, dim3(256), sweep);
+        }
+        DSM_MARK();
         hipLaunchStage(k_commit_seeds<false>, k_commit_seeds<true>, g_seed_thr, dim3(256), sweep);
         DSM_MARK();
     }

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <list>
@@ -159,7 +160,49 @@ struct Segment {
 
 struct Frame {
     dsm_stamp stamp;
-    uint8_t *bytes; // tightly packed rows in a page-locked block of the node's pool
+    uint8_t *bytes; // tightly packed rows: a page-locked block of the node's pool, or (overflow) pageable memory
+    bool pinned;
+};
+
+// Frames wait for their pose in page-locked memory so that the upload of a frame is one DMA -- but only the first
+// kPinnedFrames of each kind: the reference's subscriber queues are 5000 deep (ros_node.cpp:24-25) in PAGEABLE memory, and
+// a stalled pose source must not pin 5000 x 2.3 MB of host RAM.  The overflow lives in pageable blocks (their upload is a
+// staged copy: slower, still correct) that are freed as soon as they leave the queue; free page-locked blocks beyond
+// kPooledFrames go back to the system as well.
+constexpr size_t kPinnedFrames = 256, kPooledFrames = 64;
+
+struct FramePool {
+    std::vector<uint8_t *> free_blocks; // page-locked, ready for reuse
+    size_t pinned_live = 0;             // page-locked blocks handed out and not yet released
+    uint8_t *take(size_t bytes, bool *pinned) {
+        if (!free_blocks.empty()) {
+            uint8_t *p = free_blocks.back();
+            free_blocks.pop_back();
+            pinned_live++;
+            *pinned = true;
+            return p;
+        }
+        if (pinned_live < kPinnedFrames) {
+            void *p = nullptr;
+            if (dsm_host_alloc(&p, bytes) == DSM_OK) {
+                pinned_live++;
+                *pinned = true;
+                return (uint8_t *)p;
+            }
+        }
+        *pinned = false;
+        return (uint8_t *)malloc(bytes ? bytes : 1);
+    }
+    void release(const Frame &f) {
+        if (!f.pinned) { free(f.bytes); return; }
+        pinned_live--;
+        if (free_blocks.size() < kPooledFrames) free_blocks.push_back(f.bytes);
+        else dsm_host_free(f.bytes);
+    }
+    void drain() {
+        for (uint8_t *p : free_blocks) dsm_host_free(p);
+        free_blocks.clear();
+    }
 };
 
 } // namespace
@@ -168,7 +211,7 @@ struct dsm_surfel_map {
     dsm_surfel_map_config cfg;
     dsm_handle *engine = nullptr;
     std::list<Frame> image_buffer, depth_buffer;                                 // surfel_map.h:96-97
-    std::vector<uint8_t *> image_pool, depth_pool;                               // free page-locked blocks
+    FramePool image_pool, depth_pool;                                            // where the buffered frames' bytes live
     std::list<std::tuple<dsm_stamp, dsm_pose_msg, int>> pose_reference_buffer; // :98
     std::vector<PoseElement> poses_database;                                     // :120
     std::set<int> local_surfels_indexs;                                          // :122
@@ -361,12 +404,12 @@ int synchronize_msgs(dsm_surfel_map *m) {
         find_image = find_depth = false;
         while (!m->image_buffer.empty()) {
             const double t = to_sec(m->image_buffer.front().stamp);
-            if (t < pose_reference_time) { m->image_pool.push_back(m->image_buffer.front().bytes); m->image_buffer.pop_front(); }
+            if (t < pose_reference_time) { m->image_pool.release(m->image_buffer.front()); m->image_buffer.pop_front(); }
             else { find_image = t == pose_reference_time; lost |= !find_image; break; }
         }
         while (!m->depth_buffer.empty()) {
             const double t = to_sec(m->depth_buffer.front().stamp);
-            if (t < pose_reference_time) { m->depth_pool.push_back(m->depth_buffer.front().bytes); m->depth_buffer.pop_front(); }
+            if (t < pose_reference_time) { m->depth_pool.release(m->depth_buffer.front()); m->depth_buffer.pop_front(); }
             else { find_depth = t == pose_reference_time; lost |= !find_depth; break; }
         }
         if (!lost) break;
@@ -397,7 +440,7 @@ int synchronize_msgs(dsm_surfel_map *m) {
     return DSM_OK;
 }
 
-int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, std::vector<uint8_t *> &pool, dsm_stamp stamp, int32_t width,
+int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, FramePool &pool, dsm_stamp stamp, int32_t width,
                int32_t height, size_t step, const void *data, size_t elem) {
     if (!data) return fail(m, DSM_E_INVALID, "null image data");
     if (width != m->cfg.cam_width || height != m->cfg.cam_height)
@@ -405,25 +448,20 @@ int copy_frame(dsm_surfel_map *m, std::list<Frame> &buffer, std::vector<uint8_t 
     if (step < (size_t)width * elem) return fail(m, DSM_E_INVALID, "row step smaller than a row");
     Frame f;
     f.stamp = stamp;
-    if (!pool.empty()) {
-        f.bytes = pool.back();
-        pool.pop_back();
-    } else {
-        void *p = nullptr;
-        if (dsm_host_alloc(&p, (size_t)width * (size_t)height * elem) != DSM_OK) return fail(m, DSM_E_HIP, "no page-locked memory for a frame");
-        f.bytes = (uint8_t *)p;
-    }
+    f.bytes = pool.take((size_t)width * (size_t)height * elem, &f.pinned);
+    if (!f.bytes) return fail(m, DSM_E_HIP, "no host memory for a frame");
     for (int y = 0; y < height; y++) memcpy(f.bytes + (size_t)y * width * elem, (const uint8_t *)data + (size_t)y * step, (size_t)width * elem);
     buffer.push_back(f);
-    // frames nobody claims (no pose ever arrives for them) must not pile up in page-locked memory: the oldest go
-    // (default 5000 = the reference's subscriber queue depth, ros_node.cpp:24-25; a drop is reported, never silent)
+    // frames nobody claims (no pose ever arrives for them) must not pile up: the oldest go (default 5000 = the
+    // reference's subscriber queue depth, ros_node.cpp:24-25; a drop is reported, never silent).  Only the first
+    // kPinnedFrames of them are page-locked (FramePool).
     const int lim = m->cfg.max_buffered_frames;
     const size_t keep = lim > 0 ? (size_t)lim : lim == 0 ? (size_t)5000 : (size_t)-1;
     while (buffer.size() > keep) {
         fprintf(stderr, "dsm_surfel_map: more than %zu %s frames wait for a pose; dropping the one stamped %.6f (its pose will be skipped)\n",
                 keep, elem == 1 ? "image" : "depth", to_sec(buffer.front().stamp));
         m->frames_dropped++;
-        pool.push_back(buffer.front().bytes);
+        pool.release(buffer.front());
         buffer.pop_front();
     }
     return DSM_OK;
@@ -501,10 +539,10 @@ int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out
 void dsm_surfel_map_destroy(dsm_surfel_map *m) {
     if (!m) return;
     dsm_destroy(m->engine);
-    for (const Frame &f : m->image_buffer) dsm_host_free(f.bytes);
-    for (const Frame &f : m->depth_buffer) dsm_host_free(f.bytes);
-    for (uint8_t *p : m->image_pool) dsm_host_free(p);
-    for (uint8_t *p : m->depth_pool) dsm_host_free(p);
+    for (const Frame &f : m->image_buffer) m->image_pool.release(f);
+    for (const Frame &f : m->depth_buffer) m->depth_pool.release(f);
+    m->image_pool.drain();
+    m->depth_pool.drain();
     delete m;
 }
 

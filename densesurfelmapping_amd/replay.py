@@ -1,15 +1,38 @@
-"""Offline replay of an image/depth/pose sequence, sharded one subsequence per GPU.
+"""Offline replay of an image/depth/pose sequence, sharded one subsequence per GPU (BASELINE configs[2]).
 
 The per-frame path has a strict temporal dependency (frame t+1 fuses into the map frame t produced,
 surfel_map.cpp:161), so a single sequence does not shard; independent subsequences do (SURVEY.md
-§8(e)).  Each rank owns one GPU and one or more handles, replays its contiguous subsequence with
-keyframe indices restarting at 0, and the final clouds are merged with one all-gather of the counts
-and one all-gather of the padded clouds (RCCL over xGMI when the backend is "nccl"; the same code
-runs on "gloo" with CPU tensors in the tests).  There is no collective on the per-frame path.
+§8(e)).  Each rank owns one GPU and one handle, replays its contiguous subsequence with keyframe
+indices restarting at 0 -- frames arrive from the host, double-buffered through two frame slots, the
+map never leaves HBM -- and the final clouds are merged with one all-gather of the counts and one
+all-gather of the padded clouds (RCCL over xGMI when the backend is "nccl"; the same code runs on
+"gloo" with CPU tensors in the tests).  There is no collective on the per-frame path.
+
+    python -m densesurfelmapping_amd.replay --synthetic 4541 --gpus 8 [--out merged.npy]
+    python -m densesurfelmapping_amd.replay --kitti <seq_dir> --poses poses.txt --gpus 8
+
+`--kitti` reads the layout kitti_publisher reads (image_0/%06d.png, depth_0/%06d.npy with depth = bf / disparity,
+kitti_publisher/scripts/publisher.py:31-41) and a KITTI-format pose file (densesurfelmapping_amd/kitti.py);
+`--synthetic N` renders N frames of the synthetic drive of SURVEY.md §8(d).  Without a launcher, `--gpus G` starts G
+ranks itself (torch.distributed.run on 127.0.0.1) after checking that G devices are visible.  Parity of a sharded run
+is per subsequence: rank r's map is the reference's map of frames [a_r, b_r) fused from an empty map with keyframe
+indices restarting at 0 -- NOT a slice of the one-sequence map (surfels seen on both sides of a cut are not fused
+across it); tests/test_cpu.py::test_sharded_replay_gloo_world2 and tests/test_gpu_parity.py::test_sharded_replay_*
+check exactly that, and that the merged cloud is the concatenation of the shards in rank order.
 """
 from __future__ import annotations
 
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
 SURFEL_BYTES = 44
+KEYFRAME_EVERY = 5  # every 5th frame is a keyframe, reference index = latest keyframe
 
 
 def shard_subsequences(n_frames: int, world_size: int):
@@ -52,3 +75,200 @@ def merge_clouds(local_cloud, group=None):
     parts = [gathered[r * n_max * SURFEL_BYTES: r * n_max * SURFEL_BYTES + counts_l[r] * SURFEL_BYTES]
              for r in range(world)]
     return torch.cat(parts), counts_l
+
+
+# ---------------------------------------------------------------------------------------------- frame sources
+class SyntheticSource:
+    """The synthetic drive of SURVEY.md §8(d) (densesurfelmapping_amd/synth.py): frame t of the one long sequence."""
+
+    def __init__(self, n_frames, camera="KITTI_1226", seed=12345):
+        from . import synth
+        self.cam = getattr(synth, camera)
+        self.scene = synth.Scene(seed=seed)
+        self.n_frames = n_frames
+
+    def frames(self, a, b):
+        """(image uint8 [H,W], depth float32 [H,W], pose 4x4 cam->world) of frames a .. b-1"""
+        from . import synth
+        for t, image, depth, pose, _ in synth.sequence(self.cam, self.scene, b - a, start=a):
+            yield image, depth, pose
+
+
+class KittiSource:
+    """A KITTI odometry sequence directory in the layout kitti_publisher reads + a KITTI-format pose file."""
+
+    def __init__(self, seq_dir, poses, bf=None, n_frames=None):
+        from . import kitti
+        self.seq_dir, self.bf = seq_dir, bf if bf else kitti.BF_SEQ_00_02
+        self.poses = kitti.read_poses(poses)
+        n = 0
+        while n < len(self.poses) and all(os.path.isfile(p) for p in kitti.frame_paths(seq_dir, n)):
+            n += 1  # (publisher.py:34 stops at the first missing file)
+        self.n_frames = min(n, n_frames) if n_frames else n
+        if self.n_frames == 0:
+            raise FileNotFoundError(f"{seq_dir}: no image_0/000000.png + depth_0/000000.npy with a pose")
+        first = kitti.read_grey(kitti.frame_paths(seq_dir, 0)[0])
+        self.cam = kitti.camera_from_calib(seq_dir, first.shape[1], first.shape[0])
+
+    def frames(self, a, b):
+        from . import kitti
+        for i in range(a, b):
+            img_path, dep_path = kitti.frame_paths(self.seq_dir, i)
+            image = kitti.read_grey(img_path)
+            with np.errstate(divide="ignore"):
+                depth = (self.bf / np.load(dep_path)).astype(np.float32)  # publisher.py:37-38
+            yield image, depth, self.poses[i].astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------- the engine
+class HipEngine:
+    """One handle of the HIP engine (include/dsm.h) with a resident map: frames go up through two slots in turn on the
+    handle's upload stream while the previous frame is being fused.  There is no other engine in this package: without
+    a gfx950 device the constructor raises (DSM_E_NO_DEVICE)."""
+
+    def __init__(self, cam, device=0, capacity=0):
+        from . import api
+        self._api = api
+        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=2, surfel_capacity=capacity,
+                                                  flags=api.DSM_FLAG_UPLOAD_STREAM, pipeline_depth=1)
+        self.ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        self.n = 0
+
+    def fuse(self, image, depth, pose, ref_idx):  # SurfelMap::fuse_map (surfel_map.cpp:1060-1113) against the resident map
+        slot = self.n & 1
+        self.ff.frame_upload(slot, image, depth)
+        self.ff.fuse_frame_resident(slot, ref_idx, pose)
+        self.n += 1
+
+    def cloud(self):
+        """the final map as a numpy array of 44-byte records (synchronises)"""
+        return self.ff.map_download()
+
+    def cloud_tensor(self, torch, device):
+        """the final map as bytes in device memory (no host trip), for the RCCL merge"""
+        n = self.ff.map_size()
+        t = torch.empty(max(n, 1) * SURFEL_BYTES, dtype=torch.uint8, device=device)
+        got = self.ff.map_copy_to_device(t.data_ptr(), max(n, 1))
+        return t[: got * SURFEL_BYTES]
+
+    def close(self):
+        self.ff.close()
+
+
+def replay_shard(engine, source, a, b, keyframe_every=KEYFRAME_EVERY):
+    """Frames [a, b) of `source` through `engine`, keyframe indices restarting at 0."""
+    for k, (image, depth, pose) in enumerate(source.frames(a, b)):
+        engine.fuse(image, depth, pose, k // keyframe_every)
+    return b - a
+
+
+def run_rank(source, rank, world, *, engine_factory=None, backend="nccl", device=0, save_shards=None, out=None, group=None):
+    """What one rank of a sharded replay does; returns the summary (rank 0's carries the merged cloud's digest).
+    engine_factory(cam) -> engine: the tests' CPU stand-in goes in here; the default is the HIP engine."""
+    import torch
+    shards = shard_subsequences(source.n_frames, world)
+    a, b = shards[rank]
+    engine = engine_factory(source.cam) if engine_factory else HipEngine(source.cam, device=device)
+    t0 = time.perf_counter()
+    n = replay_shard(engine, source, a, b)
+    on_device = backend == "nccl" and hasattr(engine, "cloud_tensor")
+    if on_device:
+        cloud = engine.cloud_tensor(torch, f"cuda:{device}")  # (synchronises)
+    else:
+        mine = np.ascontiguousarray(engine.cloud())
+        cloud = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+    t_replay = time.perf_counter() - t0
+    if save_shards:
+        os.makedirs(save_shards, exist_ok=True)
+        np.save(os.path.join(save_shards, f"shard_{rank}.npy"), engine.cloud())
+    t1 = time.perf_counter()
+    if world > 1:
+        merged, counts = merge_clouds(cloud, group)
+    else:
+        merged, counts = cloud, [cloud.numel() // SURFEL_BYTES]
+    merged_np = merged.cpu().numpy()
+    t_merge = time.perf_counter() - t1
+    if hasattr(engine, "close"):
+        engine.close()
+    summary = {"rank": rank, "world": world, "frames": [a, b], "replayed": n, "surfels": counts[rank], "replay_s": round(t_replay, 3),
+               "frames_per_s": round(n / t_replay, 1) if t_replay > 0 else None, "merge_s": round(t_merge, 4), "backend": backend if world > 1 else None}
+    if rank == 0:
+        summary.update({"shards": [list(s) for s in shards], "counts": counts, "merged_surfels": int(merged_np.size // SURFEL_BYTES),
+                        "merged_sha256": hashlib.sha256(merged_np.tobytes()).hexdigest()})
+        if out:
+            from . import api
+            np.save(out, merged_np.view(api.SURFEL_DTYPE))
+    return summary
+
+
+def _self_launch(n_gpus, one_device):
+    import socket
+    import subprocess
+    import torch
+    seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not one_device and seen < n_gpus:
+        print(f"replay: --gpus {n_gpus} needs {n_gpus} visible GPUs, this box shows {seen}; nothing was replayed", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "densesurfelmapping_amd.replay"] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="sharded offline replay: one contiguous subsequence per GPU, clouds merged by all-gather")
+    src = ap.add_mutually_exclusive_group(required=True)
+    src.add_argument("--kitti", metavar="SEQ_DIR", help="KITTI odometry sequence directory in kitti_publisher's layout")
+    src.add_argument("--synthetic", type=int, metavar="N", help="N frames of the synthetic drive")
+    ap.add_argument("--poses", help="KITTI-format pose file (12 numbers per line), with --kitti")
+    ap.add_argument("--bf", type=float, help="baseline x focal: depth = bf / disparity (default 386.1448; 379.8145 for sequences 04-12)")
+    ap.add_argument("--frames", type=int, help="use only the first N frames of the KITTI sequence")
+    ap.add_argument("--camera", default="KITTI_1226", help="synthetic camera (densesurfelmapping_amd.synth)")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI; gloo moves the clouds through host memory")
+    ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--out", help="rank 0 writes the merged cloud here (.npy of 44-byte SurfelElement records)")
+    ap.add_argument("--save-shards", metavar="DIR", help="every rank writes its own map to DIR/shard_<rank>.npy")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        sys.exit("replay: --gpus must be >= 1")
+    if args.kitti and not args.poses:
+        sys.exit("replay: --kitti needs --poses")
+    if args.one_device and args.gpus > 1 and args.backend != "gloo":
+        sys.exit("replay: --one-device puts every rank on one GPU, which RCCL cannot do: use --backend gloo")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus, args.one_device))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"replay: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    device = 0 if (world == 1 or args.one_device) else int(os.environ.get("LOCAL_RANK", "0"))
+    source = KittiSource(args.kitti, args.poses, args.bf, args.frames) if args.kitti else SyntheticSource(args.synthetic, args.camera, args.seed)
+    import torch
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+    summary = run_rank(source, rank, world, backend=args.backend, device=device, save_shards=args.save_shards, out=args.out)
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, summary)
+        dist.destroy_process_group()
+    else:
+        rows = [summary]
+    if rank == 0:
+        head = dict(rows[0])
+        head["per_rank"] = [{k: r[k] for k in ("rank", "frames", "surfels", "replay_s", "frames_per_s")} for r in rows]
+        head["frames_per_s_all_ranks"] = round(sum(r["replayed"] for r in rows) / max(r["replay_s"] for r in rows), 1)
+        print(json.dumps(head))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,8 +18,9 @@
  * engine needs and the CPU reference has no counterpart for.
  *
  * Conventions: plain pointers and sizes, no exceptions; every call returns DSM_OK (0) or a
- * negative dsm_status; dsm_last_error() gives the message.  A handle owns one HIP stream and
- * all of its device buffers and is single-threaded-use (like a FusionFunctions instance,
+ * negative dsm_status; dsm_last_error() gives the message.  A handle owns its device buffers and, with
+ * pipeline_depth < 4, all of its streams (from 4 on it also launches on the device's shared per-queue streams,
+ * see dsm_config.pipeline_depth) and is single-threaded-use (like a FusionFunctions instance,
  * whose scratch buffers are members: fusion_functions.h:34-37); use one handle per
  * concurrent subsequence.  There is no CPU fallback: dsm_create fails with
  * DSM_E_NO_DEVICE when no gfx950 device is visible.
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 2
+#define DSM_ABI_VERSION 3 /* 3: the *_inv entry points (the caller's own pose inverse) */
 
 typedef enum {
     DSM_OK = 0,
@@ -86,10 +87,15 @@ typedef struct dsm_config {
     int32_t frame_slots;      /* resident frame slots in HBM; 0 = default (2) */
     uint32_t flags;           /* DSM_FLAG_* */
     int32_t pipeline_depth;   /* frames of one sequence whose superpixel stages may be in flight at once
-                                 (1, 2, 4, 8, 16 or 32); 0 = default (4).  Results do not depend on it.  From 4 on,
-                                 dsm_replay_enqueue launches the superpixel stages of depth / 2 consecutive frames as one
-                                 batch (every kernel once for all of them) while fuse + compaction of the previous
-                                 group run in frame order. */
+                                 (1, 2, 4, 8, 12, 16, 24 or 32); 0 = default (4).  Results do not depend on it.  From 4 on,
+                                 dsm_replay_enqueue launches the superpixel stages of G consecutive frames as one batch
+                                 (every kernel once for all of them) while fuse + compaction of the previous group run
+                                 in frame order: G = depth / 2 (two groups in turn) for 4 and 8, depth / 4 (four groups)
+                                 for 16 and 32, depth / 3 (three groups) for 12 and 24.  From depth 4 on the streams the
+                                 groups are launched on -- and with 12 / 24 the map stream too -- are the device's four
+                                 process-wide per-queue streams, shared with batches and other handles: they carry
+                                 launches only (graphs are captured on private streams), the handle's buffers stay its
+                                 own.  24 is the fastest single-sequence setting on MI355X. */
 } dsm_config;
 
 #define DSM_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying a hipGraph */
@@ -127,6 +133,19 @@ int dsm_fuse_initialize_map(dsm_handle *h, int reference_frame_index, const uint
 int dsm_fuse_map(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
                  const float *depth, size_t depth_step, const float *pose16, dsm_surfel *local,
                  int32_t *n_local, int32_t cap, int32_t *n_new);
+
+/* The same two calls with the world->cam matrix handed in.  FusionFunctions::fuse_initialize_map inverts the pose with the
+ * caller's matrix library (`pose.inverse()`, Eigen::Matrix4f, fusion_functions.cpp:59); Eigen is not part of this library,
+ * which uses the adjugate / determinant closed form instead -- equal to Eigen's result up to the last place, and a last
+ * place of this matrix can flip a create / delete decision downstream.  A caller that has the
+ * reference's matrix type computes inv_pose16 = pose.inverse() itself (include/dsm_fusion_functions.hpp does) and gets the
+ * arithmetic of ITS Eigen build bit for bit; NULL = the closed form. */
+int dsm_fuse_initialize_map_inv(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
+                                const float *depth, size_t depth_step, const float *pose16, const float *inv_pose16,
+                                dsm_surfel *local, int32_t n_local, dsm_surfel *new_out, int32_t new_cap, int32_t *n_new);
+int dsm_fuse_map_inv(dsm_handle *h, int reference_frame_index, const uint8_t *image, size_t img_step,
+                     const float *depth, size_t depth_step, const float *pose16, const float *inv_pose16,
+                     dsm_surfel *local, int32_t *n_local, int32_t cap, int32_t *n_new);
 
 /* Page-locked host memory for frames handed to dsm_frame_upload / dsm_fuse_*: uploads from it run at PCIe
  * rate without a staging copy.  Plain malloc'ed buffers work too, slower. */
@@ -194,11 +213,30 @@ int dsm_frame_upload(dsm_handle *h, int slot, const uint8_t *image, size_t img_s
 int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size_t img_step,
                             const void *depth_dev, size_t depth_step);
 
+/* ---- streamed input: frames of a replay arrive from host memory while earlier frames are being fused (the reference
+ * receives every frame through image_input / depth_input, surfel_map.cpp:83-101).  dsm_frame_upload_async returns at once:
+ * the copy runs on the device's upload stream, ordered behind every frame enqueued so far for this handle (which may
+ * still read the slot), and every frame enqueued AFTER the call -- alone or through a batch -- waits for it.  So a
+ * replay double-buffers in chunks: upload chunk k+1 into the slots chunk k-1 used, THEN enqueue chunk k; the uploads
+ * overlap the kernels of chunk k.  The source must be page-locked (dsm_host_alloc) and stay untouched until
+ * dsm_frame_uploads_wait (or dsm_synchronize after a frame that reads the slot).  Rows laid out with the slot pitch
+ * (dsm_frame_pitch elements per row: img_step = pitch, depth_step = 4 * pitch; the pad columns are never read) go up
+ * as one transfer per plane, any other step row by row. ---- */
+int dsm_frame_pitch(const dsm_handle *h, int32_t *pitch);
+int dsm_frame_upload_async(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
+                           size_t depth_step);
+int dsm_frame_uploads_wait(dsm_handle *h); /* blocks the host until this handle's asynchronous uploads have landed */
+
 /* enqueue SurfelMap::fuse_map for the frame in `slot` against the resident map */
 int dsm_fuse_frame_resident(dsm_handle *h, int slot, int reference_frame_index, const float *pose16);
 /* enqueue n frames: frame i uses slots[i], ref_idx[i], poses16[16*i .. 16*i+16) */
 int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx,
                        const float *poses16);
+/* the same with the caller's own pose inverses (see dsm_fuse_map_inv); inv_pose(s)16 may be NULL */
+int dsm_fuse_frame_resident_inv(dsm_handle *h, int slot, int reference_frame_index, const float *pose16,
+                                const float *inv_pose16);
+int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx,
+                           const float *poses16, const float *inv_poses16);
 int dsm_synchronize(dsm_handle *h);
 /* number of new surfels created by the last completed frame; synchronises */
 int dsm_last_new_count(dsm_handle *h, int32_t *n_new);
@@ -218,6 +256,8 @@ const char *dsm_batch_last_error(const dsm_batch *b);
 /* enqueue n_frames frames for every handle: frame i of handle j uses slots[j * n_frames + i], ref_idx[...], and
  * poses16[(j * n_frames + i) * 16 ..] */
 int dsm_batch_replay_enqueue(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx, const float *poses16);
+int dsm_batch_replay_enqueue_inv(dsm_batch *b, int32_t n_frames, const int32_t *slots, const int32_t *ref_idx,
+                                 const float *poses16, const float *inv_poses16); /* inv_poses16 laid out like poses16; may be NULL */
 /* wait for everything enqueued and report the first handle's error, if any */
 int dsm_batch_synchronize(dsm_batch *b);
 

@@ -23,11 +23,26 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "dsm.h"
 
 namespace dsm {
+
+namespace detail {
+// pose.inverse() with the CALLER's matrix library when the pose type has one (Eigen::Matrix4f in the reference,
+// fusion_functions.cpp:59): the engine then uses exactly the world->cam matrix the reference's own statement would have
+// produced in this build, whatever Eigen version / instruction set it was compiled with.  A pose type without
+// inverse() (a plain array wrapper) leaves it to the library's closed form (dsm.h, dsm_fuse_map_inv).
+template <typename Pose> struct PoseInverse {
+    template <typename P> static auto get(const P &p, Pose &out, int) -> decltype(out = p.inverse(), static_cast<const float *>(out.data())) {
+        out = p.inverse();
+        return out.data();
+    }
+    template <typename P> static const float *get(const P &, Pose &, long) { return nullptr; }
+};
+} // namespace detail
 
 class FusionFunctions {
   public:
@@ -56,11 +71,13 @@ class FusionFunctions {
         static_assert(sizeof(Surfel) == sizeof(dsm_surfel), "SurfelElement must keep the layout of elements.h:22-31");
         new_surfels.resize((size_t)n_seed_);
         int32_t n_new = 0;
-        const int rc = dsm_fuse_initialize_map(h_, reference_frame_index, (const uint8_t *)image.data, (size_t)image.step,
-                                               (const float *)depth.data, (size_t)depth.step, pose.data(),
-                                               reinterpret_cast<dsm_surfel *>(local_surfels.data()),
-                                               (int32_t)local_surfels.size(), reinterpret_cast<dsm_surfel *>(new_surfels.data()),
-                                               (int32_t)new_surfels.size(), &n_new);
+        Pose inv_store(pose);
+        const float *inv = detail::PoseInverse<Pose>::get(pose, inv_store, 0); // FF.cpp:59, in the caller's arithmetic
+        const int rc = dsm_fuse_initialize_map_inv(h_, reference_frame_index, (const uint8_t *)image.data, (size_t)image.step,
+                                                   (const float *)depth.data, (size_t)depth.step, pose.data(), inv,
+                                                   reinterpret_cast<dsm_surfel *>(local_surfels.data()),
+                                                   (int32_t)local_surfels.size(), reinterpret_cast<dsm_surfel *>(new_surfels.data()),
+                                                   (int32_t)new_surfels.size(), &n_new);
         new_surfels.resize(rc == DSM_OK ? (size_t)n_new : 0);
         return check(rc, h_);
     }
@@ -72,9 +89,11 @@ class FusionFunctions {
         static_assert(sizeof(Surfel) == sizeof(dsm_surfel), "SurfelElement must keep the layout of elements.h:22-31");
         int32_t n_local = (int32_t)local_surfels.size(), n_new = 0;
         local_surfels.resize((size_t)n_local + (size_t)n_seed_);
-        const int rc = dsm_fuse_map(h_, reference_index, (const uint8_t *)image.data, (size_t)image.step, (const float *)depth.data,
-                                    (size_t)depth.step, pose.data(), reinterpret_cast<dsm_surfel *>(local_surfels.data()),
-                                    &n_local, (int32_t)local_surfels.size(), &n_new);
+        Pose inv_store(pose);
+        const float *inv = detail::PoseInverse<Pose>::get(pose, inv_store, 0); // FF.cpp:59, in the caller's arithmetic
+        const int rc = dsm_fuse_map_inv(h_, reference_index, (const uint8_t *)image.data, (size_t)image.step, (const float *)depth.data,
+                                        (size_t)depth.step, pose.data(), inv, reinterpret_cast<dsm_surfel *>(local_surfels.data()),
+                                        &n_local, (int32_t)local_surfels.size(), &n_new);
         local_surfels.resize((size_t)n_local);
         if (n_new_out) *n_new_out = n_new;
         return check(rc, h_);

@@ -56,7 +56,8 @@ typedef struct dsm_surfel_map_config {
     int32_t surfel_capacity; /* active-map capacity, 0 = default of dsm_create */
     int32_t max_buffered_frames; /* images / depths kept waiting for a pose, oldest dropped (and reported on stderr)
                                     beyond; 0 = 5000, the depth of the reference's subscriber queues (ros_node.cpp:24-25;
-                                    its own lists behind them are unbounded, surfel_map.h:96-97); < 0 = unbounded */
+                                    its own lists behind them are unbounded, surfel_map.h:96-97); < 0 = unbounded.  Only the
+                                    first 256 waiting frames of each kind sit in page-locked memory, the rest is pageable */
 } dsm_surfel_map_config;
 
 int dsm_surfel_map_create(const dsm_surfel_map_config *cfg, dsm_surfel_map **out); /* SurfelMap::SurfelMap */

@@ -101,6 +101,7 @@ class SurfelMap {
         bool rgbd = false;
         int device = 0;
         int surfel_capacity = 0;
+        int max_buffered_frames = 0; // frames kept waiting for a pose: 0 = 5000 (ros_node.cpp:24-25), < 0 = unbounded (dsm_surfel_map.h)
     };
 
     explicit SurfelMap(const Params &p) {
@@ -118,6 +119,7 @@ class SurfelMap {
         c.rgbd = p.rgbd ? 1 : 0;
         c.device = p.device;
         c.surfel_capacity = p.surfel_capacity;
+        c.max_buffered_frames = p.max_buffered_frames;
         const int rc = dsm_surfel_map_create(&c, &m_);
         if (rc != DSM_OK) {
             m_ = nullptr;

@@ -56,6 +56,13 @@ void dsmref_set_eigen_perturb(const int *f16, const int *d16) {
 }
 #endif
 
+// the TU's own Matrix4f::inverse() (FF.cpp:59) of a column-major pose -- what a caller with the reference's matrix type
+// hands to the product's *_inv entry points (tests/golden/make_golden_inv.py records it)
+void dsmref_inverse4f(const float *pose16, float *inv16) {
+    const Eigen::Matrix4f inv = pose_from(pose16).inverse();
+    for (int i = 0; i < 16; i++) inv16[i] = inv.d[i];
+}
+
 void *dsmref_create(int w, int h, float fx, float fy, float cx, float cy, float far_d, float near_d) {
     RefHandle *r = new RefHandle();
     r->w = w;

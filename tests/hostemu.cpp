@@ -6,6 +6,7 @@
 // never loaded by the product package.
 //
 // Build: g++ -std=c++17 -O2 -ffp-contract=off -shared -fPIC tests/hostemu.cpp -o tests/_build/libhostemu.so
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -37,6 +38,12 @@ struct Emu {
     std::set<long long> unsure_waves; long long sweep_id = 0;
     long long gn_first_noncore = 0; // seeds with a residual outside the Huber core at step 1
     long long gn_seeds = 0, gn_seeds_mask_changed = 0, gn_steps = 0, gn_steps_mask_changed = 0; // Gauss-Newton steps 2..5 whose Huber classes differ from the step before
+    // exact-sum study: Gauss-Newton sums whose fp32-product terms span <= 21 binades are exact in
+    // double in ANY order; [0] fitted seeds whose step-1 sums (9 H + 4 J) all qualify, [1] of steps 2..5: J sums all
+    // qualify, [2] steps 2..5 counted, [3] qualifying sums whose tree-order value differs from the ordered one (must be 0),
+    // [4] all-core steps
+    long long exact_stats[5] = {0, 0, 0, 0, 0};
+    long long exact_operand_pass = 0; // steps 2..5 that pass the cheaper OPERAND-level test: range(r) + range(p_a) + 1 <= 21 for every a
     long long fast_total = 0, fast_unsure = 0, fast_mismatches = 0, fast_checked = 0, fast_bound_violations = 0; // pick_seed_fast
 
     float I(int x, int y) const { return (float)img[(size_t)y * img_step + x]; }
@@ -247,17 +254,52 @@ void seed_planes(Emu &e) {
                     }
                     if (it == 0) { bool any = false; for (int i = 0; i < m; i++) any = any || cls[i] != 0; if (any) e.gn_first_noncore++; }
                     if (it > 0) { e.gn_steps++; if (!same) e.gn_steps_mask_changed++; if (!same) changed_any = true; }
+                    bool all_core = true;
+                    for (int i = 0; i < m; i++) all_core = all_core && cls[i] == 0;
+                    if (all_core) e.exact_stats[4]++;
+                    bool sums_ok = all_core; // every sum of this step spans <= 21 binades
                     for (int lane = 0; lane < 20; lane++) {
                         const bool is_j = lane >= 16;
                         const int ta = lane < 16 ? (lane & 3) : ((lane - 16) & 3), tb = (lane >> 2) & 3;
                         double a = 0.0;
+                        int e_min = 1 << 30, e_max = -(1 << 30);
+                        float terms[256];
                         for (int i = 0; i < m; i++) {
                             const float p4[4] = {lp[i * 3], lp[i * 3 + 1], lp[i * 3 + 2], 1.0f};
                             const float X = is_j ? res[i] : p4[ta], Y = is_j ? p4[ta] : p4[tb];
                             a += gn_term(is_j, X, Y, cls[i], e.huber);
+                            const float t = (2 * X) * Y;
+                            terms[i] = t;
+                            if (t != 0.0f && t == t && !std::isinf(t)) { const int ex = std::ilogb(t); e_min = ex < e_min ? ex : e_min; e_max = ex > e_max ? ex : e_max; }
+                            else if (t != 0.0f) { e_max = 1 << 29; e_min = 0; } // NaN / inf: never exact
                         }
                         acc[lane] = a;
+                        // (H(3,3) is an integer count; the upper triangle repeats the lower; J lanes matter on every step, H lanes on the first)
+                        const bool counted = is_j || (it == 0 && ta <= tb && !(ta == 3 && tb == 3));
+                        if (all_core && counted) {
+                            const bool ok = e_max < e_min || e_max - e_min <= 21;
+                            sums_ok = sums_ok && ok;
+                            if (ok) { // any order gives the ordered sum's bits: check a 16-way strided tree
+                                double part[16] = {0};
+                                for (int i = 0; i < m; i++) part[i & 15] += (double)terms[i];
+                                for (int w = 8; w >= 1; w >>= 1) for (int q = 0; q < w; q++) part[q] += part[q + w];
+                                if (memcmp(&part[0], &a, sizeof a) != 0) e.exact_stats[3]++;
+                            }
+                        }
                     }
+                    if (it > 0 && all_core) {
+                        auto range_of = [&](auto get) {
+                            int lo = 1 << 30, hi = -(1 << 30);
+                            for (int i = 0; i < m; i++) { const float v = get(i); if (v != 0.0f) { const int ex = std::ilogb(v); lo = ex < lo ? ex : lo; hi = ex > hi ? ex : hi; } }
+                            return hi < lo ? 0 : hi - lo;
+                        };
+                        const int rr = range_of([&](int i) { return res[i]; });
+                        bool ok = rr <= 21;
+                        for (int a2 = 0; a2 < 3; a2++) ok = ok && rr + range_of([&](int i) { return lp[i * 3 + a2]; }) + 1 <= 21;
+                        if (ok) e.exact_operand_pass++;
+                    }
+                    if (it == 0 && sums_ok) e.exact_stats[0]++;
+                    if (it > 0) { e.exact_stats[2]++; if (sums_ok) e.exact_stats[1]++; }
                     gn_step(acc, acc + 16, nx, ny, nz, nb);
                 }
                 if (changed_any) e.gn_seeds_mask_changed++;
@@ -358,6 +400,7 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 }
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
+void emu_exact_sum_stats(void *p, long long *out) { for (int i = 0; i < 5; i++) out[i] = ((Emu *)p)->exact_stats[i]; out[5] = ((Emu *)p)->exact_operand_pass; }
 // pick_seed_fast over every pixel assigned so far: out[12] (7: seeds with a non-core residual at step 1; 8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
 // out[0..7] = [pixels, unsure, answered differently from pick_seed, costs checked,
 // bound violated, 64-pixel row segments (waves) with an unsure pixel, sweeps]

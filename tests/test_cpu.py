@@ -320,7 +320,7 @@ def test_c_abi_exports_every_declared_symbol():
         for name in declared:
             assert hasattr(lib, name), name
     lib.dsm_abi_version.restype = C.c_int
-    assert lib.dsm_abi_version() == 2
+    assert lib.dsm_abi_version() == 3
     assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
 
 
@@ -416,6 +416,70 @@ def test_merge_clouds_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+_SHARD_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from densesurfelmapping_amd import replay, synth
+from oracle.bindings import PortOracle, SURFEL_DTYPE
+class OracleEngine:  # TEST stand-in for the HIP engine: the C restatement behind the engine interface of replay.py
+    def __init__(self, cam):
+        self.orc, self.local = PortOracle(cam), np.zeros(0, SURFEL_DTYPE)
+    def fuse(self, image, depth, pose, ref_idx):
+        self.local, _ = self.orc.fuse_map(ref_idx, image, depth, pose, self.local)
+    def cloud(self):
+        return self.local
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+src = replay.SyntheticSource(int(sys.argv[2]), camera="TINY", seed=77)
+out = sys.argv[3]
+summary = replay.run_rank(src, rank, world, engine_factory=OracleEngine, backend="gloo", save_shards=out, out=os.path.join(out, "merged.npy"))
+# this rank's shard against the oracle driven directly over frames [a, b): keyframe indices restart at 0
+a, b = replay.shard_subsequences(src.n_frames, world)[rank]
+orc, lo = PortOracle(src.cam), np.zeros(0, SURFEL_DTYPE)
+for t, img, dep, pose, ref in synth.sequence(src.cam, src.scene, b - a, start=a):
+    assert ref == (t - a) // 5
+    lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+mine = np.load(os.path.join(out, f"shard_{rank}.npy"))
+assert len(lo) > 0 and mine.tobytes() == lo.tobytes(), (rank, len(mine), len(lo))
+dist.barrier()
+if rank == 0:
+    merged = np.load(os.path.join(out, "merged.npy"))
+    parts = [np.load(os.path.join(out, f"shard_{r}.npy")) for r in range(world)]
+    assert merged.tobytes() == b"".join(p.tobytes() for p in parts)
+    assert summary["counts"] == [len(p) for p in parts] and summary["merged_surfels"] == len(merged)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_replay_gloo_world2(oracle_built, tmp_path):
+    """BASELINE configs[2] end to end on the CPU side: densesurfelmapping_amd.replay's driver (frame source ->
+    shard_subsequences -> one engine per rank -> merge_clouds) with two gloo ranks and the C restatement standing in for
+    the HIP engine (injected here, the product has no such engine): rank r's map is the oracle's map of frames
+    [a_r, b_r) fused from an empty map with keyframe indices restarting at 0, and the merged cloud is the concatenation
+    of the shards in rank order."""
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARD_WORKER)
+    out = tmp_path / "shards"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), ROOT, "23", str(out)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+
+
+def test_replay_cli_refuses_without_gpus():
+    """`python -m densesurfelmapping_amd.replay --gpus N` on a box with fewer devices reports that and replays nothing;
+    with one rank and no GPU the engine itself refuses (no CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, "-m", "densesurfelmapping_amd.replay", "--synthetic", "4", "--camera", "TINY", "--gpus", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "visible GPUs" in r.stderr and "{" not in r.stdout
 
 
 # ------------------------------------------------------------------ C++ facade
@@ -841,6 +905,41 @@ def test_eigen_last_place_exposure_is_bounded(oracle_built):
             assert abs(row["final_surfels"] - row["final_surfels_baseline"]) <= 2, (name, row)
             if row["first_frame_with_other_counts"] is None:
                 assert row["integer_fields_changed"] == 0 and row["max_rel_float_drift"] < 1e-3, (name, row)
+
+
+def test_inverse_pose_golden_is_the_perturbed_reference_tu(oracle_built):
+    """tests/golden/inv_pose_perturbed.npz (what the GPU test of the *_inv entry points replays) regenerated from the
+    reference's own TU where its sources exist: the recorded inverses, counts and final map are that TU's, byte for byte;
+    everywhere: the fixture is self-consistent (the recorded inverses are the closed-form inverses moved by the recorded
+    ulps -- a float-level check that needs no reference)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "inv_pose_perturbed.npz"))
+    from densesurfelmapping_amd import synth
+    cam, scene, n = getattr(synth, str(g["camera"])), synth.Scene(seed=int(g["scene_seed"])), int(g["frames"])
+    assert g["inv_poses_cm"].shape == (n, 16) and len(g["n_new"]) == n and len(g["final_map"]) == int(g["n_local"][-1])
+    # pose * recorded inverse ~ identity (the perturbation is a few ulps)
+    for t, img, dep, pose, ridx in synth.sequence(cam, scene, n):
+        inv = g["inv_poses_cm"][t].reshape(4, 4).T.astype(np.float64)
+        assert np.allclose(np.asarray(pose, np.float64) @ inv, np.eye(4), atol=1e-4), t
+    if not os.path.isdir("/root/reference/surfel_fusion/src"):
+        return
+    subprocess.run(["make", "-s", "-C", oracle_built, "perturb"], check=True)
+    import ctypes
+    from oracle.bindings import SURFEL_DTYPE, RefOracle
+    ref = RefOracle(cam, kind="serial_perturb")
+    ref.lib.dsmref_set_eigen_perturb.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    ref.lib.dsmref_inverse4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    ulps = np.ascontiguousarray(g["ulps"], np.int32)
+    ref.lib.dsmref_set_eigen_perturb(ulps.ctypes.data_as(ctypes.c_void_p), None)
+    local = np.zeros(0, SURFEL_DTYPE)
+    for t, img, dep, pose, ridx in synth.sequence(cam, scene, n):
+        pose_cm = np.ascontiguousarray(np.asarray(pose, np.float32).T).ravel()
+        out = np.zeros(16, np.float32)
+        ref.lib.dsmref_inverse4f(pose_cm.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        assert out.tobytes() == g["inv_poses_cm"][t].tobytes(), t
+        local, k = ref.fuse_map(ridx, img, dep, pose, local)
+        assert (k, len(local)) == (int(g["n_new"][t]), int(g["n_local"][t])), t
+    assert local.tobytes() == g["final_map"].tobytes()
+    ref.lib.dsmref_set_eigen_perturb(None, None)
 
 
 def test_shipped_sources_carry_no_hooks():

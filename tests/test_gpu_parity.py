@@ -307,6 +307,118 @@ def test_batched_lockstep_replay(mods, fit_small_cap, B):
         ff.close()
 
 
+def test_caller_provided_pose_inverse(mods):
+    """DSM_ABI_VERSION 3, the *_inv entry points (include/dsm.h): the reference inverts the pose with the caller's Eigen
+    (FF.cpp:59); fed the inverses "another Eigen build" produced -- tests/golden/inv_pose_perturbed.npz, recorded from the
+    reference's own TU with every element of Matrix4f::inverse() moved by up to two ulps (make_golden_inv.py) -- the
+    engine reproduces THAT build's map byte for byte, through the drop-in call and through the resident replay; without
+    them it reproduces the unperturbed one, which differs."""
+    api, synth, ob = mods
+    g = np.load(os.path.join(ROOT, "tests", "golden", "inv_pose_perturbed.npz"))
+    cam, scene, n = getattr(synth, str(g["camera"])), synth.Scene(seed=int(g["scene_seed"])), int(g["frames"])
+    want = g["final_map"].astype(api.SURFEL_DTYPE)
+    frames = list(synth.sequence(cam, scene, n))
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    lg = np.zeros(0, api.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in frames:
+        lg, k = ff.fuse_map(ref, img, dep, pose, lg, inv_pose=g["inv_poses_cm"][t])
+        assert (k, len(lg)) == (int(g["n_new"][t]), int(g["n_local"][t])), f"frame {t}"
+    assert not fields_equal(lg, want), "drop-in with the caller's inverses"
+    ff.close()
+    # the resident replay with the same inverses
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=65536)
+    for t, img, dep, pose, ref in frames:
+        ff.frame_upload(t, img, dep)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    s, r, p = api.FusionFunctions.pack_replay([f[0] for f in frames], [f[4] for f in frames], np.stack([f[3] for f in frames]))
+    ff.replay_enqueue(s[:n - 1], r[:n - 1], p[:n - 1], inv_poses_cm=g["inv_poses_cm"][:n - 1])
+    ff.fuse_frame_resident(n - 1, frames[-1][4], frames[-1][3], inv_pose=g["inv_poses_cm"][n - 1])
+    ff.synchronize()
+    assert not fields_equal(ff.map_download(), want), "resident replay with the caller's inverses"
+    ff.close()
+    # control: the library's own closed form gives the UNperturbed TU's map, which is another one
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=65536)
+    lg = np.zeros(0, api.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in frames:
+        lg, _ = ff.fuse_map(ref, img, dep, pose, lg)
+    assert len(lg) != len(want) or fields_equal(lg, want), "the perturbation pattern of the golden must matter"
+    ff.close()
+
+
+def test_handles_and_batches_driven_from_threads(mods):
+    """The device's four per-queue streams are shared by every batch and every frame-group lead of the process; graphs are
+    captured on private streams, so threads driving different handles / batches never see each other's captures
+    (ADVICE r03): two pipelined handles (depth 4: frame groups on the shared streams) on a thread each, then eight
+    batches of two handles with a thread each -- more batches than reserved streams, all capturing their graphs at
+    their first frame at the same time.  Every map equals the same replay done on one thread."""
+    import threading
+    api, synth, ob = mods
+    cam, n = synth.TINY, 24
+    scenes = [synth.Scene(seed=400 + 3 * b) for b in range(16)]
+    seqs = [list(synth.sequence(cam, sc, n)) for sc in scenes]
+
+    def make(b, depth):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=65536, pipeline_depth=depth)
+        for t, img, dep, pose, ref in seqs[b]:
+            ff.frame_upload(t, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        return ff
+
+    def plan(b):
+        fr = seqs[b]
+        return api.FusionFunctions.pack_replay([f[0] for f in fr], [f[4] for f in fr], np.stack([f[3] for f in fr]))
+
+    want = []
+    for b in range(16):  # one thread, one handle at a time
+        ff = make(b, 1)
+        ff.replay_enqueue(*plan(b))
+        ff.synchronize()
+        want.append(ff.map_download())
+        ff.close()
+    errors = []
+
+    def guarded(fn, *a):
+        try:
+            fn(*a)
+        except Exception as e:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append(repr(e))
+
+    # two pipelined handles, a thread each
+    hs = [make(b, 4) for b in range(2)]
+    def drive_handle(b):
+        s, r, p = plan(b)
+        for lo in range(0, n, 8):  # several enqueue calls: first capture, then replays
+            hs[b].replay_enqueue(s[lo:lo + 8], r[lo:lo + 8], p[lo:lo + 8])
+        hs[b].synchronize()
+    th = [threading.Thread(target=guarded, args=(drive_handle, b)) for b in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for b in range(2):
+        assert not fields_equal(hs[b].map_download(), want[b]), f"pipelined handle {b} driven from its own thread"
+        hs[b].close()
+    # eight batches of two handles, a thread each
+    hs = [make(b, 1) for b in range(16)]
+    batches = [api.Batch(hs[2 * k:2 * k + 2]) for k in range(8)]
+    def drive_batch(k):
+        s, r, p, _ = api.Batch.pack([plan(2 * k), plan(2 * k + 1)])
+        s, r, p = s.reshape(2, n), r.reshape(2, n), p.reshape(2, n, 16)
+        for lo in range(0, n, 6):
+            batches[k].replay_enqueue(np.ascontiguousarray(s[:, lo:lo + 6]).ravel(), np.ascontiguousarray(r[:, lo:lo + 6]).ravel(),
+                                      np.ascontiguousarray(p[:, lo:lo + 6]).reshape(-1, 16), 6)
+        batches[k].synchronize()
+    th = [threading.Thread(target=guarded, args=(drive_batch, k)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for b in range(16):
+        assert not fields_equal(hs[b].map_download(), want[b]), f"handle {b} of batch {b // 2}, one thread per batch"
+    for bt in batches:
+        bt.close()
+    for ff in hs:
+        ff.close()
+
+
 def test_rgbd_constant_set(mods):
     """BASELINE config 4 shape: 640x480 with the RGB-D constants of fusion_functions.h:17-21."""
     api, synth, ob = mods
@@ -815,6 +927,73 @@ def test_message_log_replay_driver(mods, tmp_path):
 def _bench_line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _kitti_layout(tmp_path, cam, scene, n, synth):
+    """a synthetic drive written in kitti_publisher's directory layout (tests/test_cpu.py::test_kitti_layout_reader)"""
+    import struct
+    import zlib
+    from densesurfelmapping_amd import kitti
+    seq = tmp_path / "sequences" / "00"
+    (seq / "image_0").mkdir(parents=True)
+    (seq / "depth_0").mkdir()
+
+    def png(path, img):
+        h, w = img.shape
+        rows = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+        def chunk(kind, body):
+            return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+        open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                               chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b""))
+    with open(tmp_path / "poses.txt", "w") as f:
+        for t in range(n):
+            img, dep, pose = synth.render(cam, scene, t)
+            png(str(seq / "image_0" / ("%06d.png" % t)), img)
+            with np.errstate(divide="ignore"):
+                np.save(str(seq / "depth_0" / ("%06d.npy" % t)), (kitti.BF_SEQ_00_02 / dep.astype(np.float64)).astype(np.float32))
+            f.write(" ".join("%.17g" % v for v in pose.astype(np.float64)[:3].ravel()) + "\n")
+    open(seq / "calib.txt", "w").write(f"P0: {cam.fx} 0 {cam.cx} 0 0 {cam.fy} {cam.cy} 0 0 0 1 0\n")
+    return str(seq), str(tmp_path / "poses.txt")
+
+
+@pytest.mark.parametrize("source", ["synthetic", "kitti"])
+def test_sharded_replay_two_ranks_on_one_gpu(mods, tmp_path, source):
+    """BASELINE configs[2] end to end through the product's own driver, `python -m densesurfelmapping_amd.replay --gpus 2`
+    (two ranks sharing this box's one GPU, clouds merged over gloo): a sequence -- synthetic, or read from
+    kitti_publisher's on-disk layout -- is cut in two, rank r replays frames [a_r, b_r) on the HIP engine with keyframe
+    indices restarting at 0, frames streamed from the host through two slots.  Every shard's map equals the oracle's
+    for the same frames, byte for byte, and the merged cloud is the shards in rank order."""
+    import subprocess
+    import sys
+    api, synth, ob = mods
+    from densesurfelmapping_amd import replay
+    n, out = 27, tmp_path / "out"
+    if source == "synthetic":
+        src = replay.SyntheticSource(n, camera="TINY", seed=31)
+        what = ["--synthetic", str(n), "--camera", "TINY", "--seed", "31"]
+    else:
+        seq, poses = _kitti_layout(tmp_path, synth.NODE_CAM, synth.Scene(seed=9), n, synth)
+        src = replay.KittiSource(seq, poses)
+        assert src.n_frames == n and (src.cam.width, src.cam.fx) == (synth.NODE_CAM.width, synth.NODE_CAM.fx)
+        what = ["--kitti", seq, "--poses", poses]
+    r = subprocess.run([sys.executable, "-m", "densesurfelmapping_amd.replay"] + what +
+                       ["--gpus", "2", "--one-device", "--backend", "gloo", "--save-shards", str(out), "--out", str(out / "merged.npy")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    head = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    shards = replay.shard_subsequences(n, 2)
+    assert head["shards"] == [list(s) for s in shards] and head["world"] == 2
+    parts = []
+    for rank, (a, b) in enumerate(shards):
+        orc, lo = ob.PortOracle(src.cam), np.zeros(0, ob.SURFEL_DTYPE)
+        for k, (img, dep, pose) in enumerate(src.frames(a, b)):
+            lo, _ = orc.fuse_map(k // 5, img, dep, pose, lo)
+        got = np.load(out / f"shard_{rank}.npy")
+        assert len(lo) > 0 and not fields_equal(got, lo.astype(api.SURFEL_DTYPE)), f"shard {rank}: frames [{a}, {b})"
+        parts.append(got)
+    merged = np.load(out / "merged.npy")
+    assert merged.tobytes() == b"".join(p.tobytes() for p in parts) and head["counts"] == [len(p) for p in parts]
+    assert head["merged_sha256"] == hashlib.sha256(merged.tobytes()).hexdigest()
 
 
 def test_bench_two_ranks_on_one_gpu():

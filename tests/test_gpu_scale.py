@@ -142,6 +142,131 @@ def test_long_sequence_kitti_golden_batched(mods, gold):
         ff.close()
 
 
+def test_four_batches_in_flight_against_the_golden(mods, gold):
+    """The exact form bench.py times: FOUR batches of eight handles, each batch enqueued by its own host thread on its own
+    stream, all in flight at once (32 subsequences sharing the machine, graphs captured concurrently at the first
+    frame) -- here every one of the 32 replays the 200-frame 1226x370 golden sequence; each batch is checked at the
+    50-frame checkpoints and every handle's final map and label image are the reference TU's."""
+    import threading
+    api, synth, ob = mods
+    case = gold["sequence"]
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    period, n, step = scene.frames_per_period, case["frames"], case["checkpoint_every"]
+    frames = list(synth.sequence(cam, scene, n))
+    plan = api.FusionFunctions.pack_replay([f[0] % period for f in frames], [f[4] for f in frames], [f[3] for f in frames])
+    n_bat, per = 4, 8
+    handles = []
+    for _ in range(n_bat * per):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 19, pipeline_depth=1)
+        for t in range(period):
+            ff.frame_upload(t, frames[t][1], frames[t][2])
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        handles.append(ff)
+    batches = [api.Batch(handles[g * per:(g + 1) * per]) for g in range(n_bat)]
+    errors = []
+
+    def drive(g):
+        try:
+            for base in range(0, n, step):
+                for c0 in range(base, base + step, 16):  # ragged chunks, several enqueue calls between checkpoints
+                    c1 = min(base + step, c0 + 16)
+                    s_, r_, p_, m = api.Batch.pack([(plan[0][c0:c1], plan[1][c0:c1], plan[2][c0:c1])] * per)
+                    batches[g].replay_enqueue(s_, r_, p_, m)
+                batches[g].synchronize()
+                got = handles[g * per + (base // step) % per].map_download()
+                if map_sha(got, api.SURFEL_DTYPE) != case["map_sha256"][str(base + step)]:
+                    errors.append(f"batch {g}: map after {base + step} frames")
+        except Exception as e:  # noqa: BLE001 -- reported in the main thread
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=drive, args=(g,)) for g in range(n_bat)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    final = case["map_sha256"][str(n)]
+    for i, ff in enumerate(handles):
+        assert map_sha(ff.map_download(), api.SURFEL_DTYPE) == final, f"handle {i}: final map"
+        assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == case["per_frame"][-1]["labels_sha256"], f"handle {i}: labels"
+    for bt in batches:
+        bt.close()
+    for ff in handles:
+        ff.close()
+
+
+def test_long_sequence_streamed_input(mods, gold):
+    """Frames arriving from the host instead of sitting in HBM (the reference receives every frame through image_input /
+    depth_input, surfel_map.cpp:83-101): the 200-frame 1226x370 golden sequence again, every handle with only 2 x 10
+    frame slots, chunks of ten frames sent up with dsm_frame_upload_async from page-locked memory while the previous
+    chunk is being fused.  ONE pipelined handle (frame groups: the uploads are waited for on the groups' lead streams)
+    and the bench's form, EIGHT handles in one batch (handle b starts the sequence b frames late ... all pass the same
+    checkpoints).  Maps and labels are the reference TU's: streamed == resident, byte for byte."""
+    api, synth, ob = mods
+    case = gold["sequence"]
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    n, step, C = case["frames"], case["checkpoint_every"], 10
+    frames = list(synth.sequence(cam, scene, n))
+    period = scene.frames_per_period
+
+    def host_frames(ff):
+        pin = api.PinnedFrames(ff, period)  # the scene's period of frames in page-locked memory, slot pitch
+        for t in range(period):
+            pin.set(t, frames[t][1], frames[t][2])
+        return pin
+
+    def plan(lo, hi, base_slot):
+        fr = frames[lo:hi]
+        return api.FusionFunctions.pack_replay([base_slot + i for i in range(len(fr))], [f[4] for f in fr], [f[3] for f in fr])
+
+    # ---- one handle, frame groups
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=2 * C, surfel_capacity=1 << 20, pipeline_depth=8)
+    pin = host_frames(ff)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    def send(k):  # chunk k -> slot half k & 1
+        for i, t in enumerate(range(k * C, min(n, (k + 1) * C))):
+            ff.frame_upload_async((k & 1) * C + i, pin.image(t % period), pin.depth(t % period))
+    send(0)
+    for k in range(n // C):
+        if (k + 1) * C < n:
+            send(k + 1)  # BEFORE chunk k is enqueued: ordered behind chunk k - 1, which used these slots
+        ff.replay_enqueue(*plan(k * C, (k + 1) * C, (k & 1) * C))
+        if ((k + 1) * C) % step == 0:
+            assert map_sha(ff.map_download(), api.SURFEL_DTYPE) == case["map_sha256"][str((k + 1) * C)], f"streamed, one handle: after {(k + 1) * C} frames"
+    assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == case["per_frame"][-1]["labels_sha256"]
+    ff.frame_uploads_wait()
+    ff.close()
+    pin.close()
+
+    # ---- eight handles in one batch, all streaming the same sequence from one page-locked copy
+    B = 8
+    handles = [api.FusionFunctions.from_camera(cam, frame_slots=2 * C, surfel_capacity=1 << 20, pipeline_depth=1) for _ in range(B)]
+    pin = host_frames(handles[0])
+    for h in handles:
+        h.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    batch = api.Batch(handles)
+    def send_all(k):
+        for h in handles:
+            for i, t in enumerate(range(k * C, min(n, (k + 1) * C))):
+                h.frame_upload_async((k & 1) * C + i, pin.image(t % period), pin.depth(t % period))
+    send_all(0)
+    for k in range(n // C):
+        if (k + 1) * C < n:
+            send_all(k + 1)
+        s_, r_, p_, m = api.Batch.pack([plan(k * C, (k + 1) * C, (k & 1) * C)] * B)
+        batch.replay_enqueue(s_, r_, p_, m)
+        if ((k + 1) * C) % step == 0:
+            batch.synchronize()
+            for b in (0, B - 1):
+                assert map_sha(handles[b].map_download(), api.SURFEL_DTYPE) == case["map_sha256"][str((k + 1) * C)], f"streamed, batch handle {b}: after {(k + 1) * C} frames"
+    batch.synchronize()
+    for h in handles:
+        assert hashlib.sha256(h.labels().tobytes()).hexdigest() == case["per_frame"][-1]["labels_sha256"]
+        h.frame_uploads_wait()
+    batch.close()
+    for h in handles:
+        h.close()
+    pin.close()
+
+
 def _large_case(mods, gold_rows, case, dropin_trial=None):
     api, synth, ob = mods
     cam = getattr(synth, case["camera"])
