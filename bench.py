@@ -863,12 +863,14 @@ def main():
         bts = [api.Batch([hs[b] for b in grp]) for grp in groups_b]
         n_chunks = (w_s + k_s) * F // C_s
 
-        def send(g, k):  # chunk k of every subsequence of batch g -> slot half k & 1
+        def send(g, k):  # chunk k of every subsequence of batch g -> slot half k & 1, as runs of consecutive frames of the period
             for b in groups_b[g]:
-                pf = pins[scene_of[b]]
-                for i in range(C_s):
+                pf, i = pins[scene_of[b]], 0
+                while i < C_s:
                     t = (k * C_s + i + phase_of[b]) % period
-                    hs[b].frame_upload_async((k & 1) * C_s + i, pf.image(t), pf.depth(t))
+                    run_n = min(C_s - i, period - t)
+                    hs[b].frames_upload_async((k & 1) * C_s + i, pf, t, run_n)
+                    i += run_n
 
         def chunk_plan(b, k):
             lo, hi = k * C_s, (k + 1) * C_s
@@ -881,6 +883,17 @@ def main():
                 sb, rb, pb, nn = api.Batch.pack([chunk_plan(b, k) for b in groups_b[g]])
                 bts[g].replay_enqueue(sb, rb, pb, nn)
 
+        # what the link alone delivers with these transfers (no kernels running): one subsequence's chunk, 20 times
+        for h_ in hs[:2]:
+            h_.frames_upload_async(0, pins[0], 0, C_s)
+            h_.frame_uploads_wait()
+        t_l = time.perf_counter()
+        for _ in range(20):
+            for h_ in hs[:2]:  # two subsequences: one per upload stream of the device
+                h_.frames_upload_async(0, pins[0], 0, C_s)
+        for h_ in hs[:2]:
+            h_.frame_uploads_wait()
+        link_GBps = 40 * C_s * pins[0].pitch * cam.height * 5 / (time.perf_counter() - t_l) / 1e9
         for g in range(n_bat):
             send(g, 0)
         k_w = w_s * F // C_s
@@ -895,6 +908,7 @@ def main():
         fps_s = B * (n_chunks - k_w) * C_s / dt_s
         frame_bytes = pins[0].pitch * cam.height * 5  # what one frame moves over the link: pitched image + depth rows
         out["streamed_input"] = {"value": round(fps_s, 1), "unit": "frames/s", "pcie_GBps": round(fps_s * frame_bytes / 1e9, 2),
+                                 "link_alone_GBps": round(link_GBps, 2), "link_alone_frames_per_s": round(link_GBps * 1e9 / frame_bytes, 1),
                                  "bytes_per_frame": int(frame_bytes), "fraction_of_resident_rate": round(fps_s / fps, 3),
                                  "frame_slots_per_subsequence": 2 * C_s, "chunk_frames": C_s, "subsequences": B, "steps": k_s,
                                  "mean_live_surfels": round(float(np.mean([h_.map_size() for h_ in hs]))),

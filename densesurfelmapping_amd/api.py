@@ -50,7 +50,7 @@ ABI_SYMBOLS = (
     "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
     "dsm_store_deactivate", "dsm_store_activate", "dsm_store_erase", "dsm_store_warp", "dsm_store_size",
     "dsm_store_download",
-    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_frame_pitch", "dsm_frame_upload_async", "dsm_frame_uploads_wait", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
+    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_frame_pitch", "dsm_frame_upload_async", "dsm_frames_upload_async", "dsm_frame_uploads_wait", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
     "dsm_batch_replay_timed",
@@ -133,6 +133,7 @@ def load_library():
     lib.dsm_frame_upload_device.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
     lib.dsm_frame_pitch.argtypes = [_vp, _vp]
     lib.dsm_frame_upload_async.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]
+    lib.dsm_frames_upload_async.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t]
     lib.dsm_frame_uploads_wait.argtypes = [_vp]
     lib.dsm_fuse_frame_resident.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.dsm_replay_enqueue.argtypes = [_vp, C.c_int32, _vp, _vp, _vp]
@@ -389,6 +390,14 @@ class FusionFunctions:
         if image.strides[1] != 1 or depth.strides[1] != 4:
             raise ValueError("rows must be contiguous")
         self._check(self._lib.dsm_frame_upload_async(self._h, slot, _ptr(image), image.strides[0], _ptr(depth), depth.strides[0]))
+
+    def frames_upload_async(self, slot0, pinned, first, n):
+        """frames first .. first+n-1 of a PinnedFrames block (slot layout, back to back) into slots slot0 .. slot0+n-1:
+        one transfer per plane for all of them"""
+        assert 0 <= first and first + n <= pinned.n and (pinned.h, pinned.w) == (self.height, self.width)
+        img, dep = pinned.image(first), pinned.depth(first)
+        self._check(self._lib.dsm_frames_upload_async(self._h, slot0, n, _ptr(img), img.strides[0], pinned.pitch * pinned.h,
+                                                      _ptr(dep), dep.strides[0], pinned.pitch * pinned.h * 4))
 
     def frame_uploads_wait(self):
         self._check(self._lib.dsm_frame_uploads_wait(self._h))

@@ -34,7 +34,8 @@ constexpr int kDefaultCapacity = 4 * 1024 * 1024;
 constexpr int kBatchStreams = 4;
 hipError_t batch_streams_reserve(int device); // see BatchStreamPool
 hipStream_t batch_stream_at(int device, int i);
-hipStream_t device_upload_stream(int device); // asynchronous frame uploads of every handle on the device (dsm_frame_upload_async)
+constexpr int kUploadStreams = 2;
+hipStream_t device_upload_stream(int device, int *which); // asynchronous frame uploads of the handles on the device (dsm_frame_upload_async)
 constexpr uint64_t kBatchBit = 1ull << 62;    // up_pending: a batch stream has not waited for this handle's latest upload yet
 
 } // namespace
@@ -171,6 +172,7 @@ struct dsm_handle {
     // stream, kBatchBit: a batch stream)
     hipEvent_t ev_up = nullptr;
     uint64_t up_pending = 0;
+    int up_which = -1; // which of the device's upload streams this handle's uploads take (dealt out at its first upload)
     int64_t frames_submitted = 0, frames_done = 0;
     int batches_joined = 0; // dsm_batch_create copied this handle's context: it must not change any more
     int map_upper = 0; // host-side upper bound of the resident map size
@@ -1344,28 +1346,52 @@ int dsm_frame_pitch(const dsm_handle *h, int32_t *pitch) {
 }
 
 int dsm_frame_upload_async(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth, size_t depth_step) {
+    return dsm_frames_upload_async(h, slot, 1, image, img_step, 0, depth, depth_step, 0);
+}
+
+int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *image, size_t img_step, size_t img_frame_step,
+                            const float *depth, size_t depth_step, size_t depth_frame_step) {
     if (!h) return DSM_E_INVALID;
     if (!image || !depth) return fail(h, DSM_E_INVALID, "null image/depth");
-    if (slot < 0 || slot >= h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slot %d out of range [0,%d)", slot, h->hc.n_slots);
+    if (n < 1 || slot0 < 0 || slot0 + n > h->hc.n_slots) return fail(h, DSM_E_INVALID, "frame slots [%d,%d) out of range [0,%d)", slot0, slot0 + n, h->hc.n_slots);
     const int w = h->hc.w, hh = h->hc.h, pitch = h->hc.pitch;
     if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
+    if (n > 1 && (img_frame_step < img_step * (size_t)hh || depth_frame_step < depth_step * (size_t)hh)) return fail(h, DSM_E_INVALID, "frame step smaller than a frame");
     int rc = bind_device(h);
     if (rc) return rc;
-    hipStream_t up = device_upload_stream(h->device);
+    hipStream_t up = device_upload_stream(h->device, &h->up_which);
     if (!up) return fail(h, DSM_E_HIP, "no upload stream on device %d", h->device);
     if (!h->ev_up) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
     // behind every frame enqueued so far for this handle (its map stream runs fuse + tail of every frame after the
-    // superpixel stages that read the slots, and waits for the batches the handle takes part in): they may read this slot
+    // superpixel stages that read the slots, and waits for the batches the handle takes part in): they may read these slots
     HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(up, h->ev_fence, 0));
-    uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot * h->hc.slot_elems;
-    float *dd = (float *)h->hc.depth_base + (int64_t)slot * h->hc.slot_elems;
-    // rows laid out with the slot's own pitch go up as ONE transfer per plane; any other step row by row (a 2-D copy is
-    // hundreds of small DMA transfers: correct, and several times slower)
-    if (img_step == (size_t)pitch) HIP_TRY(h, hipMemcpyAsync(di, image, (size_t)pitch * (size_t)(hh - 1) + (size_t)w, hipMemcpyHostToDevice, up));
-    else HIP_TRY(h, hipMemcpy2DAsync(di, (size_t)pitch, image, img_step, (size_t)w, (size_t)hh, hipMemcpyHostToDevice, up));
-    if (depth_step == (size_t)pitch * 4) HIP_TRY(h, hipMemcpyAsync(dd, depth, ((size_t)pitch * (size_t)(hh - 1) + (size_t)w) * 4, hipMemcpyHostToDevice, up));
-    else HIP_TRY(h, hipMemcpy2DAsync(dd, (size_t)pitch * 4, depth, depth_step, (size_t)w * 4, (size_t)hh, hipMemcpyHostToDevice, up));
+    uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot0 * h->hc.slot_elems;
+    float *dd = (float *)h->hc.depth_base + (int64_t)slot0 * h->hc.slot_elems;
+    const size_t plane = (size_t)pitch * (size_t)hh; // elements of one slot
+    // Rows laid out with the slot's own pitch go up as ONE transfer per plane -- and n frames laid out back to back like
+    // the slots themselves as one transfer per plane for all of them (a transfer costs ~10 us before its first byte:
+    // two per frame hold a 2.4 MB frame to a third of the link's rate).  Any other row step goes row by row (a 2-D copy
+    // is hundreds of small DMA transfers: correct, and several times slower).
+    const bool img_flat = img_step == (size_t)pitch, dep_flat = depth_step == (size_t)pitch * 4;
+    if (img_flat && (n == 1 || img_frame_step == plane)) {
+        HIP_TRY(h, hipMemcpyAsync(di, image, plane * (size_t)(n - 1) + (size_t)pitch * (size_t)(hh - 1) + (size_t)w, hipMemcpyHostToDevice, up));
+    } else {
+        for (int i = 0; i < n; i++) {
+            const uint8_t *src = image + (size_t)i * img_frame_step;
+            if (img_flat) HIP_TRY(h, hipMemcpyAsync(di + (size_t)i * plane, src, (size_t)pitch * (size_t)(hh - 1) + (size_t)w, hipMemcpyHostToDevice, up));
+            else HIP_TRY(h, hipMemcpy2DAsync(di + (size_t)i * plane, (size_t)pitch, src, img_step, (size_t)w, (size_t)hh, hipMemcpyHostToDevice, up));
+        }
+    }
+    if (dep_flat && (n == 1 || depth_frame_step == plane * 4)) {
+        HIP_TRY(h, hipMemcpyAsync(dd, depth, (plane * (size_t)(n - 1) + (size_t)pitch * (size_t)(hh - 1) + (size_t)w) * 4, hipMemcpyHostToDevice, up));
+    } else {
+        for (int i = 0; i < n; i++) {
+            const float *src = (const float *)((const char *)depth + (size_t)i * depth_frame_step);
+            if (dep_flat) HIP_TRY(h, hipMemcpyAsync(dd + (size_t)i * plane, src, ((size_t)pitch * (size_t)(hh - 1) + (size_t)w) * 4, hipMemcpyHostToDevice, up));
+            else HIP_TRY(h, hipMemcpy2DAsync(dd + (size_t)i * plane, (size_t)pitch * 4, src, depth_step, (size_t)w * 4, (size_t)hh, hipMemcpyHostToDevice, up));
+        }
+    }
     HIP_TRY(h, hipEventRecord(h->ev_up, up));
     h->up_pending = ~0ull;
     return DSM_OK;
@@ -1589,7 +1615,8 @@ struct BatchStreamPool {
     hipStream_t st[64][kBatchStreams] = {};
     bool made[64] = {};
     int next[64] = {};
-    hipStream_t up[64] = {}; // asynchronous frame uploads, created at the first dsm_frame_upload_async on the device
+    hipStream_t up[64][kUploadStreams] = {}; // asynchronous frame uploads, created at the first dsm_frame_upload_async on the device
+    int up_next[64] = {};
 } g_batch_streams;
 
 // (The reserved streams live as long as the process, like the HIP context they belong to: a static destructor would run
@@ -1614,15 +1641,17 @@ hipStream_t batch_stream_at(int device, int i) {
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
     return g_batch_streams.made[device] ? g_batch_streams.st[device][i] : nullptr;
 }
-// ONE upload stream per device, shared by its handles (a stream per handle would spread the handles' own streams
-// unevenly over the hardware queues, see DSM_FLAG_UPLOAD_STREAM in dsm.h): the copies are DMA transfers ordered by events,
-// they need no queue of their own per subsequence.
-hipStream_t device_upload_stream(int device) {
+// TWO upload streams per device, shared by its handles (a stream per handle would spread the handles' own streams
+// unevenly over the hardware queues, see DSM_FLAG_UPLOAD_STREAM in dsm.h): the copies are DMA transfers ordered by
+// events, they need no queue of their own per subsequence -- but one stream's transfers run one after the other on one
+// DMA engine (36.7 GB/s of 1226x370 frames on this box); two keep two engines busy.  which < 0: deal the next one out.
+hipStream_t device_upload_stream(int device, int *which) {
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
-    if (!g_batch_streams.up[device] && hipStreamCreateWithFlags(&g_batch_streams.up[device], hipStreamNonBlocking) != hipSuccess)
-        g_batch_streams.up[device] = nullptr;
-    return g_batch_streams.up[device];
+    if (*which < 0) *which = g_batch_streams.up_next[device]++ % kUploadStreams;
+    hipStream_t &st = g_batch_streams.up[device][*which];
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    return st;
 }
 hipStream_t batch_stream_take(int device) {
     if (device < 0 || device >= 64) return nullptr;

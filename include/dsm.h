@@ -225,6 +225,12 @@ int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size
 int dsm_frame_pitch(const dsm_handle *h, int32_t *pitch);
 int dsm_frame_upload_async(dsm_handle *h, int slot, const uint8_t *image, size_t img_step, const float *depth,
                            size_t depth_step);
+/* n frames into slots slot0 .. slot0+n-1: frame i at image + i * img_frame_step / depth + i * depth_frame_step (bytes).
+ * Frames laid out back to back exactly like the slots (row steps = the pitch, frame steps = pitch * height elements) go
+ * up as ONE transfer per plane for all n -- a replay that keeps its frames in that layout pays two transfers per chunk
+ * instead of two per frame. */
+int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *image, size_t img_step, size_t img_frame_step,
+                            const float *depth, size_t depth_step, size_t depth_frame_step);
 int dsm_frame_uploads_wait(dsm_handle *h); /* blocks the host until this handle's asynchronous uploads have landed */
 
 /* enqueue SurfelMap::fuse_map for the frame in `slot` against the resident map */

@@ -166,6 +166,15 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
     assert pixels >= frames * 3 * cam.width * cam.height * 0.9 and checked > pixels
     assert mismatches == 0 and violations == 0, (mismatches, violations)
     assert unsure < 0.02 * pixels, (unsure, pixels)
+    # the exact-sum claim behind k_seed_fit's tree-ordered Jacobian sums (dsm_kernels.hip, row16_sum): fp32-product terms
+    # spanning <= 21 binades sum exactly in double in ANY order -- on every qualifying sum of every fitted seed a 16-way
+    # tree gives the ordered sum's bits, and nearly every all-core step qualifies
+    ex = (C.c_longlong * 6)()
+    emu.lib.emu_exact_sum_stats.argtypes = [C.c_void_p, C.c_void_p]
+    emu.lib.emu_exact_sum_stats(emu.h, ex)
+    assert ex[3] == 0, f"{ex[3]} qualifying sums whose tree-order value differs from the ordered one"
+    assert ex[2] == 0 or ex[1] >= 0.95 * ex[2], (ex[1], ex[2])
+    print(f"exact sums: steps 2..5 whose Jacobian sums all span <= 21 binades: {ex[1]} of {ex[2]}; step-1 (H and J): {ex[0]} of {st[8]} seeds; tree == ordered on all")
     print(f"plane fit: {st[7]} of {st[8]} seeds with a residual outside the Huber core at step 1, {st[9]} with a class change later")
     print(f"pick_seed_fast: {unsure} of {pixels} pixels unsure ({100.0 * unsure / pixels:.3f} %), {checked} costs within their bound")
 

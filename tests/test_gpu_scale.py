@@ -243,10 +243,9 @@ def test_long_sequence_streamed_input(mods, gold):
     for h in handles:
         h.map_upload(np.zeros(0, api.SURFEL_DTYPE))
     batch = api.Batch(handles)
-    def send_all(k):
+    def send_all(k):  # (period = 5 chunks of ten: a chunk is ten consecutive frames of the page-locked block -> one transfer per plane)
         for h in handles:
-            for i, t in enumerate(range(k * C, min(n, (k + 1) * C))):
-                h.frame_upload_async((k & 1) * C + i, pin.image(t % period), pin.depth(t % period))
+            h.frames_upload_async((k & 1) * C, pin, (k * C) % period, C)
     send_all(0)
     for k in range(n // C):
         if (k + 1) * C < n:
