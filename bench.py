@@ -60,29 +60,35 @@ def stage_alg_bytes(stage, n, n_seed, m_avg, k_avg):
 KERNEL_OF_STAGE = {
     "init_seeds": "k_init_seeds", "assign_0": "k_assign<true>", "assign_1": "k_assign<false>", "assign_2": "k_assign<false>",
     "resolve_1": "k_resolve", "resolve_2": "k_resolve",
-    "update_seeds_0": "k_update_seeds<false>", "update_seeds_1": "k_update_seeds<true>", "update_seeds_2": "k_update_seeds<true>",
+    "update_seeds_0": "k_update_seeds", "update_seeds_1": "k_update_seeds", "update_seeds_2": "k_update_seeds",
     "commit_seeds_0": "k_commit_seeds", "commit_seeds_1": "k_commit_seeds", "commit_seeds_2": "k_commit_seeds",
     "seed_points": "k_seed_points", "seed_fit": "k_seed_fit", "fuse_surfels": "k_fuse_surfels", "frame_tail": "k_frame_tail",
 }
 BATCHED_KERNELS_OF_STAGE = {
     "assign_0": ["k_assign<true, true, 4>"], "assign_1": ["k_assign<false, true, 4>"], "assign_2": ["k_assign<false, true, 4>"],
-    "update_seeds_0": ["k_update_seeds<false, true>", "k_update_seeds_rest<false, true>"],
-    "update_seeds_1": ["k_update_seeds<true, true>", "k_update_seeds_rest<true, true>"],
-    "update_seeds_2": ["k_update_seeds<true, true>", "k_update_seeds_rest<true, true>"],
+    "update_seeds_0": ["k_update_seeds<true>", "k_update_seeds_rest<true>"],
+    "update_seeds_1": ["k_update_seeds<true>", "k_update_seeds_rest<true>"],
+    "update_seeds_2": ["k_update_seeds<true>", "k_update_seeds_rest<true>"],
+    "resolve_1": ["k_resolve<true>", "k_apply_labels<true>"], "resolve_2": ["k_resolve<true>", "k_apply_labels<true>"],
     "seed_points": ["k_pixel_normals<true>", "k_seed_stats<true>"],
     "seed_fit": ["k_seed_fit<true, 1>", "k_seed_fit<true, 2>", "k_seed_finish<true>"],
 }
-PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r03_pmc_traffic.json", "r03_pmc_traffic_batched.json", "r03_pmc_sq_batch8.md"
+PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r04_pmc_traffic.json", "r04_pmc_traffic_batched.json", "r04_pmc_sq_batch8.md"
+DEFAULT_SUBSEQUENCES = 128  # batched mode: 4 batches of 32 (round 4; 32 in 4 batches of 8 until then)
 
 
-def pmc_traffic(kernels, name):
+def pmc_traffic(kernels, name, per_launch=None):
     """HBM-side bytes per launch of the given kernel(s) (summed) from the committed rocprofv3 --pmc passes of this round
     (FETCH_SIZE and WRITE_SIZE collected in separate runs, tools/gpu_pmc.sh; the JSON records them with the calibration
-    used).  Counters cannot be read from inside the run; None when no measurement is on file."""
+    used).  Counters cannot be read from inside the run; None when no measurement is on file (per_launch: only a record of
+    launches batched over that many subsequences counts)."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, None
-    table = json.load(open(path)).get("kernels", {})
+    rec = json.load(open(path))
+    if per_launch is not None and rec.get("subsequences_per_launch") != per_launch:
+        return None, None
+    table = rec.get("kernels", {})
     if isinstance(kernels, str):
         kernels = [kernels]
     recs = [table.get(k) for k in kernels]
@@ -93,7 +99,7 @@ def pmc_traffic(kernels, name):
 
 def valu_issue(fps_per_gpu, clock_ghz=None):
     """The roof that binds the batched superpixel stages: VALU instruction issue.  Wave-instructions per frame from the
-    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r03_pmc_sq_batch8.md;
+    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r04_pmc_sq_batch8.md;
     the counts are per launch, a frame launches the sweep kernels two or three times) against what 1 024 SIMDs issue at one
     wave64 instruction per 4 cycles.  clock_ghz: the shader clock sampled during the timed region (2.4 GHz assumed when it
     could not be read).  None when no pass is on file."""
@@ -116,9 +122,10 @@ def valu_issue(fps_per_gpu, clock_ghz=None):
                 pass
     if not per_launch:
         return None
-    twice = ("k_assign<false, true, 4>", "k_update_seeds<true, true>", "k_update_seeds_rest<true, true>", "k_resolve<true>")
+    twice = ("k_assign<false, true, 4>", "k_resolve<true>", "k_apply_labels<true>")
     launches = {k: 2 for k in twice}
-    launches["k_commit_seeds<true>"] = 3
+    for k in ("k_commit_seeds<true>", "k_update_seeds<true>", "k_update_seeds_rest<true>"):
+        launches[k] = 3
     per_frame = sum(v * launches.get(k, 1) for k, v in per_launch.items() if not k.startswith("k_repack")) / 8.0
     ghz = clock_ghz or 2.4
     peak = 256 * 4 * ghz * 1e9 / 4.0
@@ -317,7 +324,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSM_BENCH_STREAMS", "0")),
-                    help="independent subsequences (handles) per GPU; 0 = 32 in batched mode, 8 in streams mode")
+                    help=f"independent subsequences (handles) per GPU; 0 = {DEFAULT_SUBSEQUENCES} in batched mode, 8 in streams mode")
     ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSM_BENCH_FRAMES_PER_STEP", "32")),
                     help="frames every subsequence advances per step")
     ap.add_argument("--mode", choices=("batched", "streams"), default=os.environ.get("DSM_BENCH_MODE", "batched"),
@@ -346,7 +353,7 @@ def main():
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}), or let "
                  f"`python bench.py --gpus {args.gpus}` launch them")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    B, K, W, F = args.streams or (32 if args.mode == "batched" else 8), args.steps, args.warmup, args.frames_per_step
+    B, K, W, F = args.streams or (DEFAULT_SUBSEQUENCES if args.mode == "batched" else 8), args.steps, args.warmup, args.frames_per_step
     period = 50
     extras = rank == 0 and world == 1 and not args.no_dropin
 
@@ -607,15 +614,19 @@ def main():
             achb = algb / (dom_usb * 1e-6) / 1e9
             # (a batched stage may be two or three kernels: the lane-per-seed forms)
             fn_b = BATCHED_KERNELS_OF_STAGE.get(dom_stages[-1]) or [dom_fn[:-1] + ", true>" if dom_fn.endswith(">") else dom_fn + "<true>"]
-            traffic_b, traffic_src_b = pmc_traffic(fn_b, PMC_TRAFFIC_BATCHED) if nb == 8 else (None, None)
+            traffic_b, traffic_src_b = pmc_traffic(fn_b, PMC_TRAFFIC_BATCHED, nb)
             out["roofline_single_launch"] = out["roofline"]
             out["roofline"] = {"bound": "hbm", "kernel": " + ".join(fn_b), "stage": dom_fn, "launches_per_frame": len(dom_stages), "subsequences_per_launch": nb,
                                "achieved": round(achb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achb / HBM_PEAK_GBS, 5),
                                "traffic": traffic_b,
-                               "traffic_source": (f"profiles/{traffic_src_b} (rocprofv3 --pmc of launches batched over 8 subsequences, separate passes)"
+                               "traffic_source": (f"profiles/{traffic_src_b} (rocprofv3 --pmc of launches batched over {nb} subsequences, separate passes)"
                                                   if traffic_src_b else None),
                                "event_overhead_us": round(ovb, 2), "alg_bytes_per_launch": int(algb), "avg_launch_us": round(dom_usb, 2),
                                "frames_timed": int(nfb), "mean_live_surfels": round(mtb), "mean_new_surfels": round(kb, 1),
+                               "timing": "HIP events between the kernels of an eager replay of ONE batch alone on the GPU, the empty-interval "
+                                         "overhead (event_overhead_us) subtracted; `rocprofv3 --kernel-trace` of the same launches: "
+                                         "profiles/r04_kernel_trace_batch32x1.md; in the timed region four batches share the machine and a "
+                                         "launch takes longer (profiles/r04_kernel_trace_batch32x4_default.md)",
                                "note": "the timed region launches every kernel once per batch of subsequences; roofline_single_launch is the "
                                        "same kernel launched for one subsequence"}
             out["batched_kernel_us"] = {k: round(v, 2) for k, v in perb.items()}

@@ -1238,9 +1238,9 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
 
 // ---- seed statistics without a wave per seed
 // k_pixel_normals, one thread per pixel: the forward-difference normal (FF.cpp:664-712) of every pixel that is a depth
-// inlier of its own superpixel (FF.cpp:846-850: member, depth > 0.05, |mean depth - depth| < HUBER_RANGE) and zero for
-// every other pixel -- a 12 B/pixel plane that lives in L2 between two kernels.  (calculate_pixels_norms computes all of
-// them; only these are ever read, FF.cpp:852-857.)
+// inlier of its own superpixel (FF.cpp:846-850: member, depth > 0.05, |mean depth - depth| < HUBER_RANGE), written into
+// a 12 B/pixel plane; the other pixels' entries are stale and never read.  (calculate_pixels_norms computes all of them;
+// only these are ever read, FF.cpp:852-857.)
 template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
@@ -1254,39 +1254,44 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(con
     const unsigned p = (unsigned)(__mul24(y, pitch) + x), p4 = p << 2;
     const float d = ld_off(dep, p4);
     const int l = ld_off(c->label, p4);
-    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-    const bool interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2; // FF.cpp:670-677
-    if (l >= 0 && interior && d > flt_below(0.05)) {                   // (double)d > 0.05
-        const float md = ld_off(reinterpret_cast<const float *>(c->core), ((unsigned)l << 4) + 12u);
-        const float d_right = ld_off(dep, p4 + 4u), d_down = ld_off(dep, p4 + ((unsigned)pitch << 2));
-        const float rx0 = ld_off(c->ray_x, (unsigned)x << 2), rx1 = ld_off(c->ray_x, ((unsigned)x << 2) + 4u);
-        const float ry0 = ld_off(c->ray_y, (unsigned)y << 2), ry1 = ld_off(c->ray_y, ((unsigned)y << 2) + 4u);
-        if (fabsf(md - d) < flt_above(c->huber)) pixel_normal_rays(rx0, rx1, ry0, ry1, d, d_right, d_down, nx, ny, nz);
+    // only the depth inliers of their own superpixel are ever read (k_seed_stats asks for exactly those): nothing is
+    // stored for any other pixel; an inlier on the image border has no normal (FF.cpp:670-677) and stores zeros
+    if (!(l >= 0 && d > flt_below(0.05))) return;                      // (double)d > 0.05
+    const float md = ld_off(reinterpret_cast<const float *>(c->core), ((unsigned)l << 4) + 12u);
+    const bool interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2;
+    float d_right = 0.0f, d_down = 0.0f;
+    if (interior) { // (neighbours fetched before the inlier test is known: one round trip)
+        d_right = ld_off(dep, p4 + 4u);
+        d_down = ld_off(dep, p4 + ((unsigned)pitch << 2));
     }
+    const float rx0 = ld_off(c->ray_x, (unsigned)x << 2), rx1 = ld_off(c->ray_x, ((unsigned)x << 2) + 4u);
+    const float ry0 = ld_off(c->ray_y, (unsigned)y << 2), ry1 = ld_off(c->ray_y, ((unsigned)y << 2) + 4u);
+    if (!(fabsf(md - d) < flt_above(c->huber))) return;
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    if (interior) pixel_normal_rays(rx0, rx1, ry0, ry1, d, d_right, d_down, nx, ny, nz);
     float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(c->normals) + p * 12u);
     o[0] = nx; o[1] = ny; o[2] = nz;
 }
 
 // k_seed_stats, ONE LANE PER SEED (64 consecutive seeds per wave): calculate_sp_depth_norms up to the plane fit's
 // starting point (FF.cpp:813-871) and the head of get_huber_norm (FF.cpp:111-120).  A lane walks its seed's 16x16 window
-// twice in row-major order: once over labels and depths (member count with depth, radius, depth inliers, the ordered
-// sums of their back-projected points), once over labels and the normal plane (ordered sum of the inliers' normals:
-// k_pixel_normals left zero wherever a pixel is not an inlier of its own superpixel, and a running sum that starts at
-// +0 is unchanged by adding +0).  The wave-per-seed form spent 611 VALU instructions per seed on this, most of them
-// per-seed bookkeeping and six-lane sums; a lane spends ~26 per window pixel for 64 seeds at once.
-struct StatRow { // one window row of one lane: labels and depths, or labels and normals
+// twice in row-major order: once over labels and depths (member count with depth, radius, depth inliers and which
+// pixels they are, the ordered sums of their back-projected points), once over the normal plane for exactly those pixels
+// (ordered sum of the inliers' normals; a pixel that is no inlier adds +0, which leaves a running sum that starts at +0
+// unchanged, bit for bit).  The wave-per-seed form spent 611 VALU instructions per seed on this, most of them per-seed
+// bookkeeping and six-lane sums; a lane spends ~26 per window pixel for 64 seeds at once.
+struct StatRow { // one window row of one lane: labels and depths
     int4 lab[4];
     float4 dp[4];
-};
-struct NormRow {
-    int4 lab[4];
-    float4 nv[12]; // 16 pixels x 3 floats
 };
 template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
+    // which pixels of every window row are depth inliers of the lane's seed (bit j = window column j): found by the first
+    // walk, and all the second walk needs to know -- it fetches normals only for the quads that hold one and no labels at all
+    __shared__ unsigned short s_inl[kWin + 2][64];
     const int lane = lane_id();
     const int S = c->n_seed;
     const int s = (((S + 63) >> 6) - 1 - blk.x) * 64 + lane; // bottom rows first, see seed_of_block
@@ -1302,6 +1307,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
     const float md = core.w;
     const float hr_above = flt_above(c->huber); // the Huber class tests in fp32 (dsm_math.h)
     const int s_match = live ? s : -2;          // no label is -2
+    s_inl[kWin][lane] = s_inl[kWin + 1][lane] = 0; // (the second walk's loop runs two rows past the window)
     int qx[4];                                  // window quads as pixel offsets within a row, redirected into the row (see k_update_seeds)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -1345,6 +1351,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
         const int yc = y < 0 ? 0 : (y > h ? h : y);
         const float ry = ld_off(c->ray_y, (unsigned)yc << 2);
         const float ey = (float)y - core.y, eyy = ey * ey;
+        unsigned bits = 0u;
 #pragma unroll
         for (int j = 0; j < kWin; j++) {
             const bool mem = comp(A.lab[j >> 2], j & 3) == s_row && col_in[j];
@@ -1355,14 +1362,16 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
             n += ok ? 1 : 0;
             const bool inl = ok && fabsf(md - d) < hr_above;    // (double)r < hr && (double)r > -hr
             m_in += inl ? 1 : 0;
+            bits |= inl ? 1u << j : 0u;
             sx += inl ? rx[j] * d : 0.0f;                       // back_project (FF.cpp:91-97), summed in window order (FF.cpp:111-116)
             sy += inl ? ry * d : 0.0f;
             sz += inl ? d : 0.0f;
             if ((j & 3) == 3) {
-                asm volatile("" : "+v"(n), "+v"(m_in), "+v"(far2), "+v"(sx), "+v"(sy), "+v"(sz)); // see k_update_seeds
+                asm volatile("" : "+v"(n), "+v"(m_in), "+v"(far2), "+v"(sx), "+v"(sy), "+v"(sz), "+v"(bits)); // see k_update_seeds
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        s_inl[r][lane] = (unsigned short)bits;
     };
     {
         StatRow B0 = load_a(0), B1 = load_a(1), B2 = load_a(2), B3;
@@ -1389,26 +1398,34 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
         fit = false;
     }
     float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    wave_lds_sync();
     if (__ballot(fit) != 0) {
-        // ---- second walk: labels and normals
+        // ---- second walk: the normals of the depth inliers, in window order (k_pixel_normals left zero where an inlier
+        // has no normal).  A lane fetches the twelve floats of a quad only if the quad holds one of its inliers: on
+        // average a window's 64 quads hold inliers in 20, so two thirds of the plane's lines are never asked for -- this
+        // walk used to pull every window's 4.6 KB of labels and normals through an L2 that four frames share.
+        struct NormRowM {
+            unsigned m;
+            float4 nv[12]; // 16 pixels x 3 floats
+        };
         auto load_b = [&](int r) {
-            NormRow R;
+            NormRowM R;
+            R.m = fit ? (unsigned)s_inl[r][lane] : 0u;
             const unsigned row = row_offset(r);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const unsigned o = row + (unsigned)qx[q];
-                R.lab[q] = ld_vec<int4>(c->label, o << 2);
+                if ((R.m >> (4 * q)) & 0xfu) {
 #pragma unroll
-                for (int t = 0; t < 3; t++) R.nv[3 * q + t] = ld_vec<float4>(c->normals, o * 12u + 16u * t);
+                    for (int t = 0; t < 3; t++) R.nv[3 * q + t] = ld_vec<float4>(c->normals, o * 12u + 16u * t);
+                }
             }
             return R;
         };
-        auto walk_b = [&](const NormRow &A, int r) {
-            const int y = wy0 + r;
-            const int s_row = (r < kWin && (unsigned)y < (unsigned)h) ? s_match : -2;
+        auto walk_b = [&](const NormRowM &A) {
 #pragma unroll
             for (int j = 0; j < kWin; j++) {
-                const bool mem = comp(A.lab[j >> 2], j & 3) == s_row && col_in[j];
+                const bool mem = (A.m >> j) & 1u;
                 const int e = 3 * (j & 3); // the pixel's three floats within its quad's twelve
                 nx += mem ? comp(A.nv[3 * (j >> 2) + (e >> 2)], e & 3) : 0.0f;
                 ny += mem ? comp(A.nv[3 * (j >> 2) + ((e + 1) >> 2)], (e + 1) & 3) : 0.0f;
@@ -1419,18 +1436,18 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
                 }
             }
         };
-        NormRow B0 = load_b(0), B1 = load_b(1), B2;
+        NormRowM B0 = load_b(0), B1 = load_b(1), B2;
 #pragma unroll 1
-        for (int r = 0; r < kWin; r += 3) { // 18 rows: the two past the window are clamped re-reads, masked by their row test
+        for (int r = 0; r < kWin; r += 3) { // 18 rows: the two past the window hold no inlier
             B2 = load_b(r + 2);
             __builtin_amdgcn_sched_barrier(0);
-            walk_b(B0, r);
-            B0 = load_b(r + 3);
+            walk_b(B0);
+            B0 = load_b(r + 3 < kWin + 2 ? r + 3 : kWin + 1);
             __builtin_amdgcn_sched_barrier(0);
-            walk_b(B1, r + 1);
-            B1 = load_b(r + 4);
+            walk_b(B1);
+            B1 = load_b(r + 4 < kWin + 2 ? r + 4 : kWin + 1);
             __builtin_amdgcn_sched_barrier(0);
-            walk_b(B2, r + 2);
+            walk_b(B2);
         }
     }
     if (!live) return;

@@ -45,7 +45,7 @@ def single_name(k):
     if base == "k_assign":  # <FIRST, BATCH, pixels per thread>
         args = args[:1]
     elif base == "k_update_seeds_wave":  # the one-subsequence form of the update_seeds stage
-        base, args = "k_update_seeds", args[:1]
+        base, args = "k_update_seeds", []
     elif args[-1] == "false":
         args = args[:-1]
     return base + ("<" + ", ".join(args) + ">" if args else "")
