@@ -99,10 +99,12 @@ typedef struct dsm_config {
 } dsm_config;
 
 #define DSM_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying a hipGraph */
-#define DSM_FLAG_UPLOAD_STREAM 2u /* dsm_frame_upload runs on a stream of its own, overlapping the frames in flight
-                                     on other slots (live feeds).  Off by default: HIP spreads streams over 4
-                                     hardware queues in creation order, and one more stream per handle spreads the
-                                     map streams of many handles unevenly (8-subsequence replay: -22 %). */
+#define DSM_FLAG_UPLOAD_STREAM 2u /* dsm_frame_upload (the blocking call) runs on a stream of its own, overlapping the
+                                     frames in flight on other slots (live feeds: the node).  Off by default: HIP spreads
+                                     streams over 4 hardware queues in creation order, and one more stream per handle
+                                     spreads the map streams of many handles unevenly (8-subsequence replay: -22 %).
+                                     Handles of a batch cannot have it; replays that stream their frames -- batched or
+                                     not -- use dsm_frames_upload_async, which needs no flag and no stream per handle. */
 
 #define DSM_FLAG_WAVE_STAMPS 4u /* debug: allocate the per-wave phase-stamp buffer read by dsm_debug_wave_stamps */
 

@@ -204,6 +204,28 @@ def test_api_errors_are_reported(mods):
     assert ei.value.code == -4
     with pytest.raises(ValueError):
         ff.fuse_map(0, img[:, :-1], dep, pose, np.zeros(0, api.SURFEL_DTYPE))
+    # the asynchronous uploads (ABI 3): slot ranges and frame steps are checked before anything is enqueued
+    pin = api.PinnedFrames(ff, 3)
+    assert pin.pitch == ff.frame_pitch() and pin.pitch % 64 == 0 and pin.pitch >= cam.width
+    for i in range(3):
+        pin.set(i, img, dep)
+    with pytest.raises(api.DsmError) as ei:  # three frames into two slots
+        ff.frames_upload_async(0, pin, 0, 3)
+    assert ei.value.code == -1
+    with pytest.raises(api.DsmError) as ei:
+        ff.frame_upload_async(2, pin.image(0), pin.depth(0))
+    assert ei.value.code == -1
+    ff.frames_upload_async(0, pin, 1, 2)  # a legal one: both slots, one transfer per plane
+    ff.frame_uploads_wait()
+    ff.fuse_frame_resident(1, 0, pose)
+    ff.synchronize()
+    want, _ = ob.PortOracle(cam).fuse_map(0, img, dep, pose, np.zeros(0, ob.SURFEL_DTYPE))
+    assert not fields_equal(ff.map_download(), want.astype(api.SURFEL_DTYPE))
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    pin.close()
+    with pytest.raises(api.DsmError) as ei:  # an injected label image must hold superpixel indices (it is used as an index)
+        ff.debug_set_labels(0, np.full((cam.height, cam.width), ff.n_seed, np.int32))
+    assert ei.value.code == -1
     # capacity overflow while appending new surfels is reported, not silently truncated
     ff.frame_upload(0, img, dep)
     nearly_full = np.zeros(120, api.SURFEL_DTYPE)  # live surfels far behind the camera: never touched, never holes
