@@ -80,7 +80,7 @@ struct DeviceCtx {
     float *rest_list;       // [ceil(S / 64)][kRestListCap][64] depth lists of the queued seeds, entry-major within a group of 64
     GnHeader *gn_hdr; // [S]
     float4 *plane;    // [S] the plane k_seed_fit fitted (normal, offset: before plane_finish), for k_seed_finish
-    float *normals;   // [h][pitch][3] forward-difference normal of every depth inlier of its own superpixel, zero elsewhere (k_pixel_normals)
+    float *normals;   // [h][pitch][3] forward-difference normal of every depth inlier of its own superpixel (k_pixel_normals); other entries stale, never read
     dsm_seed *seeds; // [S] final seed table, reference layout
     // what initialize_surfels (FF.cpp:315-361) would create from each seed, prepared by k_seed_planes (every
     // input but the `fused` flag is known there): the surfel, whether the seed qualifies, the flag itself
