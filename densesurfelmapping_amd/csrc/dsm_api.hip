@@ -880,7 +880,6 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
             CREATE_TRY(hipEventCreateWithFlags(&pp.ev_map, hipEventDisableTiming));
         }
         CREATE_TRY(dev_alloc(h, &q.label, (size_t)c.slot_elems));
-        CREATE_TRY(dev_alloc(h, &q.label_alt, (size_t)c.slot_elems));
         CREATE_TRY(dev_alloc(h, &q.cand, (size_t)c.slot_elems));
         CREATE_TRY(dev_alloc(h, &q.worklist, (size_t)c.slot_elems));
         CREATE_TRY(dev_alloc(h, &q.core, (size_t)c.n_seed));
@@ -898,9 +897,9 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(dev_alloc(h, &q.fused_flag, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.seed_weight, (size_t)c.n_seed));
         CREATE_TRY(dev_alloc(h, &q.spawn_idx, (size_t)c.n_seed));
-        int32_t *ps = nullptr; // work_count, cursor, assign_done, fit_big_count, rest_count[3]
+        int32_t *ps = nullptr; // work_count, cursor, fit_big_count, rest_count[3][2]
         CREATE_TRY(dev_alloc(h, &ps, 64));
-        q.work_count = ps + 0; q.cursor = ps + 8; q.assign_done = ps + 16; q.fit_big_count = ps + 24; q.rest_count = ps + 32;
+        q.work_count = ps + 0; q.cursor = ps + 8; q.fit_big_count = ps + 24; q.rest_count = ps + 32;
         q.fit_small_cap = kFitSmallCap;
         CREATE_TRY(dev_alloc(h, &q.cur, 1));
         CREATE_TRY(dev_alloc(h, &q.rest_list, (size_t)((c.n_seed + 63) / 64) * kRestListCap * 64));
@@ -1515,7 +1514,7 @@ int dsm_debug_get_label_buffer(dsm_handle *h, int which, int32_t *out) {
     int rc = bind_device(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(out, (size_t)h->hc.w * 4, which ? h->hc.label_alt : h->hc.label, (size_t)h->hc.pitch * 4,
+    HIP_TRY(h, hipMemcpy2D(out, (size_t)h->hc.w * 4, h->hc.label, (size_t)h->hc.pitch * 4,
                            (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyDeviceToHost));
     return DSM_OK;
 }
@@ -1534,7 +1533,7 @@ int dsm_debug_set_label_buffer(dsm_handle *h, int which, const int32_t *in) {
                 return fail(h, DSM_E_INVALID, "label %d at (%d, %d) is not a superpixel index of this %d-seed grid", l, x, y, h->hc.n_seed);
         }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(which ? h->hc.label_alt : h->hc.label, (size_t)h->hc.pitch * 4, in, (size_t)h->hc.w * 4,
+    HIP_TRY(h, hipMemcpy2D(h->hc.label, (size_t)h->hc.pitch * 4, in, (size_t)h->hc.w * 4,
                            (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyHostToDevice));
     return DSM_OK;
 }

@@ -59,9 +59,7 @@ struct DeviceCtx {
     int64_t slot_elems; // pitch * h
     int32_t n_slots;
     // superpixel state
-    int32_t *label; // [h][pitch] superpixel index of every pixel (final; sweeps ping-pong with label_alt)
-    int32_t *label_alt;
-    int32_t *assign_done; // block ticket of k_assign (the last block to finish runs the resolve step)
+    int32_t *label; // [h][pitch] superpixel index of every pixel: every sweep's image in turn (k_apply_labels works in place), then the final one
     int32_t *cand;  // [h][pitch] seed picked by this sweep before the stable-skip rule is applied
     float4 *core;   // [S] x, y, mean_intensity, mean_depth  (live seed state during the sweeps)
     double *inv_depth; // [S] 1.0 / mean_depth, FF.cpp:380

@@ -149,8 +149,6 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DSM_G(img_base);
     DSM_G(depth_base);
     DSM_G(label);
-    DSM_G(label_alt);
-    DSM_G(assign_done);
     DSM_G(cand);
     DSM_G(core);
     DSM_G(inv_depth);
@@ -411,7 +409,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *label_in = ((sweep - 1) & 1) ? c->label_alt : c->label; // sweep >= 1
+    const int32_t *label_in = c->label; // the previous sweep's image (sweep >= 1)
     const int w = c->w, h = c->h, pitch = c->pitch, gw = c->gw, gh = c->gh;
     const int bx = blk.x * kTileW, by = blk.y * kTileH;
     const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
@@ -452,9 +450,9 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         const int p = (int)p0 + r * pitch;
         const unsigned p4 = (unsigned)p << 2;
         if (!has_candidate_cell(x, y, gw, gh)) {
-            // ragged border beyond every cell's reach: label -1 in both label buffers, once per frame (no later stage
-            // reads or writes these pixels: every seed window ends before them)
-            if (FIRST) c->label[p] = c->label_alt[p] = -1;
+            // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
+            // every seed window ends before them, and k_apply_labels keeps a -1)
+            if (FIRST) c->label[p] = -1;
             continue;
         }
         // the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast); the few
@@ -500,7 +498,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_resolve(const Dev
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    resolve_worklist(c, ((sweep - 1) & 1) ? c->label_alt : c->label);
+    resolve_worklist(c, c->label);
 }
 
 // Ordered sum of one Huber-Newton pass (FF.cpp:536-549): element i adds lt[i] = 2*r if its residual is
@@ -575,7 +573,7 @@ __device__ __forceinline__ float huber_passes_wave(const float *dl, float *lt, i
 constexpr int kWin = 2 * kCell; // 16
 
 // The label image of a sweep >= 1 is  new(p) = T[old(p)] < p ? pick(p) : old(p)  (see k_assign): k_apply_labels forms it,
-// once per pixel, before the seeds are updated; the label buffers take turns (sweep_labels).
+// once per pixel and in place, before the seeds are updated.
 // Second half of update_seeds for one seed (one wave): the sums of its members are in the lanes' registers, the
 // member depths > 0.1 in window row-major order in dl[0..nd).
 __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__ c, int sweep, int s, int lane, int wx0, int wy0,
@@ -618,10 +616,6 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
     }
 }
 
-// the buffer that holds the label image while the seeds of `sweep` are updated: sweep 0 writes `label` (k_assign), every
-// later sweep is applied from the previous sweep's buffer into the other one; after the last sweep (2) the image is in `label`
-__device__ __forceinline__ int32_t *sweep_labels(const DeviceCtx *c, int sweep) { return (sweep & 1) ? c->label_alt : c->label; }
-
 // update_seeds for ONE seed by one whole wave (lanes cover the 16x16 window, 4 pixels each): the form every seed took
 // until round 3.  Today it serves launches for one handle or a few, and the seeds whose depth list outgrows the
 // lane-per-seed kernel's longest LDS rows (below).  s is wave-uniform; dl / lt are two lists of 256 floats in LDS owned
@@ -632,7 +626,7 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *lbl = sweep_labels(c, sweep);
+    const int32_t *lbl = c->label;
     const int w = c->w, h = c->h, pitch = c->pitch;
     int gx, gy;
     seed_cell(c, s, gx, gy);
@@ -679,11 +673,13 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
 }
 
 // ---- the label image of a sweep >= 1, one thread per four pixels of a row:  new(p) = T[old(p)] < p ? pick(p) : old(p)
-// with T = tmin after k_resolve (see k_assign).  Until round 4 every seed's window walk formed it on the fly for the 256
-// pixels of its window -- every pixel four times over, each time behind a gather of tmin[old label] by 64 lanes that
-// hold 64 different seeds -- and the registers of that (two more row planes, the gathered tmin) held the lane-per-seed
-// kernel to one wave per SIMD.  Here a pixel is resolved once, and neighbouring pixels mostly share their old label: a
-// wave's gather touches a handful of lines.  Pixels beyond every cell's reach keep their -1 (no seed, no tmin).
+// with T = tmin after k_resolve (see k_assign), IN PLACE: a pixel's new label needs nothing but its own old one, and most
+// pixels keep theirs -- only quads in which a label changes are stored.  Until round 4 every seed's window walk formed
+// the new labels on the fly for the 256 pixels of its window -- every pixel four times over, each time behind a gather of
+// tmin[old label] by 64 lanes that hold 64 different seeds -- and the registers of that (two more row planes, the
+// gathered tmin) held the lane-per-seed kernel to one wave per SIMD.  Here a pixel is resolved once, and neighbouring
+// pixels mostly share their old label: a wave's gather touches a handful of lines.  Pixels beyond every cell's reach keep
+// their -1 (no seed, no tmin).
 template <bool BATCH> __global__ __launch_bounds__(256) void k_apply_labels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
@@ -694,14 +690,18 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_apply_labels(cons
     if (4 * xq >= pitch || y >= c->h) return;
     const int key0 = __mul24(y, pitch) + 4 * xq;
     const unsigned o4 = (unsigned)key0 << 2;
-    const int4 lab = ld_vec<int4>(sweep_labels(c, sweep - 1), o4), cd = ld_vec<int4>(c->cand, o4);
+    const int4 lab = ld_vec<int4>(c->label, o4), cd = ld_vec<int4>(c->cand, o4);
     const int l[4] = {lab.x, lab.y, lab.z, lab.w}, pk[4] = {cd.x, cd.y, cd.z, cd.w};
     int t[4], o[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) t[j] = l[j] >= 0 ? ld_off(c->tmin, (unsigned)l[j] << 2) : kIntMax;
+    bool changed = false;
 #pragma unroll
-    for (int j = 0; j < 4; j++) o[j] = t[j] < key0 + j ? pk[j] : l[j];
-    *reinterpret_cast<int4 *>(reinterpret_cast<char *>(sweep_labels(c, sweep)) + o4) = make_int4(o[0], o[1], o[2], o[3]);
+    for (int j = 0; j < 4; j++) {
+        o[j] = t[j] < key0 + j ? pk[j] : l[j];
+        changed = changed || o[j] != l[j];
+    }
+    if (changed) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(c->label) + o4) = make_int4(o[0], o[1], o[2], o[3]);
 }
 
 // One Huber-Newton pass (FF.cpp:536-553) of up to 64 seeds at once, one chain per lane: a = ordered sum of 2*r over the
@@ -811,7 +811,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *lbl = sweep_labels(c, sweep);
+    const int32_t *lbl = c->label;
     const int w = c->w, h = c->h, pitch = c->pitch;
     // bottom rows first, see seed_of_block
     const int s = (((S + 63) >> 6) - 1 - blk.x) * 64 + lane;

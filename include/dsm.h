@@ -277,8 +277,8 @@ int dsm_seed_count(const dsm_handle *h);
 /* ---- state-level test taps (poke superpixel state, run single stages) ------------------
  * Stage indices are positions in the frame's kernel sequence: 0 init_seeds, 1 assign_0, 2 update_seeds_0,
  * 3 commit_seeds_0, 4 assign_1, 5 resolve_1, 6 update_seeds_1, 7 commit_seeds_1, 8 assign_2, 9 resolve_2,
- * 10 update_seeds_2, 11 commit_seeds_2, 12 seed_points, 13 seed_fit, 14 fuse_surfels, 15 frame_tail.  Labels of sweep 0 and
- * 2 live in buffer 0, of sweep 1 in buffer 1. */
+ * 10 update_seeds_2, 11 commit_seeds_2, 12 seed_points, 13 seed_fit, 14 fuse_surfels, 15 frame_tail.  The label image is
+ * updated in place from sweep to sweep (ABI 3; `which` = 0 or 1 names the same buffer: the sweeps used to take turns). */
 int dsm_debug_run_stages(dsm_handle *h, int slot, int reference_frame_index, const float *pose16, int first_stage,
                          int last_stage);
 int dsm_debug_get_label_buffer(dsm_handle *h, int which, int32_t *out);
