@@ -143,10 +143,11 @@ def test_long_sequence_kitti_golden_batched(mods, gold):
 
 
 def test_four_batches_in_flight_against_the_golden(mods, gold):
-    """The exact form bench.py times: FOUR batches of eight handles, each batch enqueued by its own host thread on its own
-    stream, all in flight at once (32 subsequences sharing the machine, graphs captured concurrently at the first
-    frame) -- here every one of the 32 replays the 200-frame 1226x370 golden sequence; each batch is checked at the
-    50-frame checkpoints and every handle's final map and label image are the reference TU's."""
+    """The exact form bench.py times: FOUR batches of 32 handles, each batch enqueued by its own host thread on its own
+    stream, all in flight at once (128 subsequences sharing the machine, four of them per XCD in every launch, graphs
+    captured concurrently at the first frame) -- here every one of the 128 replays the 200-frame 1226x370 golden
+    sequence; each batch is checked at the 50-frame checkpoints and every handle's final map and label image are the
+    reference TU's."""
     import threading
     api, synth, ob = mods
     case = gold["sequence"]
@@ -154,7 +155,7 @@ def test_four_batches_in_flight_against_the_golden(mods, gold):
     period, n, step = scene.frames_per_period, case["frames"], case["checkpoint_every"]
     frames = list(synth.sequence(cam, scene, n))
     plan = api.FusionFunctions.pack_replay([f[0] % period for f in frames], [f[4] for f in frames], [f[3] for f in frames])
-    n_bat, per = 4, 8
+    n_bat, per = 4, 32
     handles = []
     for _ in range(n_bat * per):
         ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 19, pipeline_depth=1)
