@@ -779,19 +779,22 @@ __device__ __forceinline__ float huber_pass_regs(const float (&v)[kRestRegs], in
 // label image it reads is the sweep's own (k_apply_labels): 193 registers, two waves per SIMD where the form that
 // applied the labels inside the walk (round 3: two more row planes, a gathered tmin per pixel) held one.
 // What the first Huber pass does not finish goes to k_update_seeds_rest through two queues: the 13 % of the seeds that
-// need more passes, packed 64 to a wave again, and the seeds whose list does not fit an LDS row of kLaneCap depths (a
-// superpixel averages 53, the longest of 64 neighbours ~95; 0.05 % of all seeds have more than 127), which get a wave
+// need more passes, packed 64 to a wave again, and the seeds whose list does not fit the 123 depths a lane keeps in LDS (a
+// superpixel averages 53, the longest of 64 neighbours ~95; 0.05 % of all seeds have more), which get a wave
 // of their own.  Same arithmetic on every path, so which one a seed takes changes nothing in its result.
 // (Round 4 measured the occupancy lever of VERDICT r03 in this form: rows of 79 depths -- 20 KB, eight waves per CU
 // instead of five -- with a second lane-per-seed pass over the 10 % longer lists, long rows, seeds taken from a queue:
 // bit-exact, and slower in every configuration on one box, 26.5 k against 28.8-30.6 k frames/s for 32 subsequences in 4
 // batches, 30.5 k against 31.7 k for 128: the second pass is a full window walk again and sits between two launches
 // that wait for it.  tools/_exp/r04_update_twotier.patch.)
-constexpr int kLaneCap = kRestListCap; // + the spare row: 32 KB per wave, five waves per CU
+constexpr int kLaneCap = kRestListCap; // rows of rest_list; k_update_seeds keeps kLaneCap + 1 rows in LDS: 32 KB per wave, five waves per CU
 // rest_count[2 * sweep + ...] (zeroed by k_init_seeds) / where the queues live in `worklist` (free between k_resolve and
 // the next k_assign): entries of seeds that need more Huber passes (int4, from 0) | seeds queued for a wave of their own
 enum { kQueueRest = 0, kQueueWave = 1 };
 __device__ __forceinline__ int32_t *queue_wave(const DeviceCtx *c) { return c->worklist + 4 * c->n_seed; }
+// After the sweeps the same words hold the order in which k_seed_fit of a batched launch takes the seeds, four per wave
+// (k_seed_stats: by length of list within every 64 seeds; k_seed_points: as they come).
+__device__ __forceinline__ int32_t *fit_order(const DeviceCtx *c) { return c->worklist + 4 * c->n_seed; }
 
 struct LaneRow { // one window row of one lane: 16 labels, depths, intensities
     int4 lab[4];
@@ -800,12 +803,12 @@ struct LaneRow { // one window row of one lane: 16 labels, depths, intensities
 };
 
 template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
-    constexpr int CAP = kLaneCap;
+    constexpr int CAP = kLaneCap - 3; // the longest list kept here: 124 rows + the four a quad may add before the end is clamped
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    __shared__ __attribute__((aligned(16))) float s_list[(CAP + 1) * 64]; // [element][lane] + one spare row
+    __shared__ __attribute__((aligned(16))) float s_list[(CAP + 4) * 64]; // [element][lane] + four spare rows: 32 KB
     const int lane = lane_id();
     const int S = c->n_seed;
     const FrameParams &fp = frame_params(c);
@@ -832,10 +835,11 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
         const int x = wx0 + 4 * q;
         qx[q] = x < 0 ? 0 : (x > pitch - 4 ? pitch - 4 : x);
     }
-    // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute
-    bool col_stat[kWin];
+    // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute.  What a label of window
+    // column j is compared with: the seed, or no label at all where the column is outside
+    int s_col[kWin];
 #pragma unroll
-    for (int j = 0; j < kWin; j++) col_stat[j] = (unsigned)(wx0 + j) < (unsigned)(w - 1);
+    for (int j = 0; j < kWin; j++) s_col[j] = (unsigned)(wx0 + j) < (unsigned)(w - 1) ? s_match : -2;
 
     auto load_row = [&](int r) {
         LaneRow R;
@@ -866,26 +870,34 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     // one window row of every lane's seed: membership, sums, depth list
     auto process_row = [&](const LaneRow &A, int r) {
         const int y = wy0 + r;
-        const int s_row = (unsigned)y < (unsigned)(h - 1) ? s_match : -2;
-        // branch-free: every lane is a different seed, so a branch here only adds exec-mask bookkeeping.  The depth is
-        // stored at the list's end unconditionally and the end advances only past a member depth > 0.1 (a later store
-        // overwrites a rejected one; elements from CAP on collapse into the spare row CAP).
+        // Branch-free within the row (every lane is a different seed: a branch per pixel only adds exec-mask bookkeeping),
+        // and every per-pixel condition is ONE vector compare whose lane mask the next instruction consumes: the column's
+        // validity sits in the value the label is compared with (s_col), the row's in the exec mask of the whole row, and
+        // the depth test reads the depth already masked by membership.  (Conditions combined as lane masks cost two
+        // scalar instructions per pixel between two vector ones, and a wave of this kernel mostly has its SIMD to itself:
+        // nothing hides the hand-over.)  The depth is stored at the list's end unconditionally and the end advances
+        // only past a member depth > 0.1 (a later store overwrites a rejected one); the end is clamped to row CAP once
+        // per quad -- a quad adds at most four rows, the spare ones -- and sticks there: a list that reaches CAP is `over`.
+        if ((unsigned)y < (unsigned)(h - 1)) {
 #pragma unroll
-        for (int j = 0; j < kWin; j++) {
-            const bool mem = comp(A.lab[j >> 2], j & 3) == s_row && col_stat[j];
-            const int pi = (int)((A.im[j >> 2] >> (8 * (j & 3))) & 0xffu);
-            acc_ci += mem ? pi | 0x10000 : 0;
-            colcnt[j] += mem ? 1 : 0;
-            const float d = comp(A.dp[j >> 2], j & 3);
-            const bool dv = mem && d > flt_below(0.1); // FF.cpp:508, (double)d > 0.1
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(s_list) + (tail < tail_cap ? tail : tail_cap)) = d;
-            tail += dv ? 256u : 0u;
-            sum += dv ? d : 0.0f; // (+0.0f: the running sum of positive depths is never -0)
-            if ((j & 3) == 3) {
-                // pin the accumulators per quad: left alone, the optimiser reassociates the integer sums of the unrolled
-                // pixels into one tree and keeps every lane mask alive for it (they spill to VGPR lanes)
-                asm volatile("" : "+v"(acc_ci), "+v"(sum), "+v"(tail), "+v"(colcnt[j - 3]), "+v"(colcnt[j - 2]), "+v"(colcnt[j - 1]), "+v"(colcnt[j]));
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < kWin; j++) {
+                const bool mem = comp(A.lab[j >> 2], j & 3) == s_col[j];
+                const int pi = (int)((A.im[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                acc_ci += mem ? pi | 0x10000 : 0;
+                colcnt[j] += mem ? 1 : 0;
+                const float d = comp(A.dp[j >> 2], j & 3);
+                const float dm = mem ? d : 0.0f;
+                const bool dv = dm > flt_below(0.1); // FF.cpp:508, (double)d > 0.1
+                if ((j & 3) == 0) tail = tail < tail_cap ? tail : tail_cap;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(s_list) + tail) = d;
+                tail += dv ? 256u : 0u;
+                sum += dv ? dm : 0.0f; // (+0.0f: the running sum of positive depths is never -0)
+                if ((j & 3) == 3) {
+                    // pin the accumulators per quad: left alone, the optimiser reassociates the integer sums of the unrolled
+                    // pixels into one tree and keeps every lane mask alive for it (they spill to VGPR lanes)
+                    asm volatile("" : "+v"(acc_ci), "+v"(sum), "+v"(tail), "+v"(colcnt[j - 3]), "+v"(colcnt[j - 2]), "+v"(colcnt[j - 1]), "+v"(colcnt[j]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         const int cnt_now = acc_ci >> 16;
@@ -919,7 +931,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     const int nd = (int)((tail - lane4) >> 8);
     const bool empty = stats && cnt == 0;
     if (empty) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(S, s)], s); // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
-    const bool over = stats && nd > CAP;
+    const bool over = stats && nd >= CAP;
     const bool fin = stats && cnt > 0 && !over;
     int acc_x = 0;
 #pragma unroll
@@ -1109,6 +1121,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int s = __builtin_amdgcn_readfirstlane(seed_of_block(blk.x, wv, c->gw, c->gh)); // scalar, see k_update_seeds
     if (s < 0) return;
+    if (BATCH && lane == 0) fit_order(c)[s] = s;
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
@@ -1450,6 +1463,19 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
             walk_b(B2);
         }
     }
+    // ---- the order in which k_seed_fit takes this wave's 64 seeds, four per wave: by the length of their lists.  A
+    // group of four pads its lists to the longest one's multiple of 8 and every ordered sum runs that far, so four
+    // neighbours in the grid cost their longest list each (a quarter of all seeds gets no plane at all and sits between
+    // the others): grouped by length, the element loops of a frame shrink by 15 % and 6 % of the groups have nothing to
+    // do.  The fit's results do not depend on which seeds share a wave.  rank = number of smaller keys; the lane breaks
+    // ties, and the lanes past the last seed come last.
+    {
+        const unsigned key = ((live ? (fit ? (unsigned)(m_in + 7) >> 3 : 0u) : 0xffffu) << 6) | (unsigned)lane;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) rank += (unsigned)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
+        fit_order(c)[(((S + 63) >> 6) - 1 - blk.x) * 64 + rank] = live ? s : -1;
+    }
     if (!live) return;
     GnHeader hd;
     hd.m_in = 0;
@@ -1560,8 +1586,9 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     constexpr int kChunks = FitShape<TIER>::kChunks;
     const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
     const int S = c->n_seed;
-    const int s = s0 + g;
-    const bool live = s < S;
+    // the seed in slot s0 + g: batched launches take the seeds in the order the stage before left (fit_order)
+    const int s = TIER == kFitAll ? s0 + g : (s0 + g < S ? fit_order(c)[s0 + g] : -1);
+    const bool live = TIER == kFitAll ? s < S : s >= 0;
     stamp(c, 4, s0, 0, lane);
     const FrameParams &fp = frame_params(c);
     const double hr = c->huber;

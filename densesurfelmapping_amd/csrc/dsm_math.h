@@ -177,6 +177,7 @@ DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float seed_inv_f, 
 struct PickQuad {
     float sx[4], sy[4], si[4], sd[4], sinv[4]; // candidate k = (x offset k >> 1, y offset k & 1), the reference's scan order
     bool col_ok[2], row_in[2];                  // in the grid and, for columns, past the distance filter
+    bool depth_ok[2];                           // [row offset]: both candidates of that row either out of play or with a mean depth
     int gx0, gy0;
 };
 template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, int gh, LoadSeedF load) {
@@ -195,17 +196,18 @@ template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, in
         gy = gy < 0 ? 0 : (gy > gh - 1 ? gh - 1 : gy);
         load(gx, gy, q.sx[k], q.sy[k], q.si[k], q.sd[k], q.sinv[k]);
     }
+    for (int j = 0; j < 2; j++)
+        q.depth_ok[j] = !q.row_in[j] | ((!q.col_ok[0] | (q.sd[j] > 0)) & (!q.col_ok[1] | (q.sd[2 + j] > 0))); // (no short cuts: lane masks)
     return q;
 }
 DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pix_d, int gw) {
     const float invd = pixel_inv_depth(pix_d);
     const bool row_ok[2] = {q.row_in[0], q.row_in[1] && y % kCell != kCell / 2};
     bool live[4];
-    bool all_depth = invd > 0;
-    for (int k = 0; k < 4; k++) {
-        live[k] = q.col_ok[k >> 1] && row_ok[k & 1];
-        all_depth = all_depth && (!live[k] || q.sd[k] > 0);
-    }
+    for (int k = 0; k < 4; k++) live[k] = q.col_ok[k >> 1] && row_ok[k & 1];
+    // every live candidate has a mean depth (and the pixel a depth): per row offset that is known for the whole quadrant
+    // (depth_ok); the upper row is out of play altogether for a pixel on the filter's edge
+    const bool all_depth = invd > 0 && q.depth_ok[0] && (q.depth_ok[1] || y % kCell == kCell / 2);
     // FF.cpp:442-451: with every candidate's depth term applied the pick is the argmin with it, else the argmin without.
     // Costs are >= 0, so their bit patterns order like the values; the candidate's position in the reference's scan goes
     // into the two lowest bits (a change of < 4 ulp, inside the error bound): the smallest tagged cost names the winner.
