@@ -1596,9 +1596,47 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     GnHeader hd;
     hd.m_in = 0;
     float4 core = make_float4(0, 0, 0, 0);
+    // Everything a lane will want from memory is asked for at once, before anything is waited for: the seed's header, and
+    // this lane's window row (labels, depths, the rays of the sixteen columns) for the gather below -- whether the seed has
+    // a list at all is in the header, but a wave of this kernel lives as long as its round trips take (a third of a
+    // wave's life was waiting: for the header, then for the rows, then for one ray per inlier column, each in turn).
+    int4 row_lab[4];
+    float4 row_dp[4];
+    float row_rx[kWin], row_ry = 0.0f;
+    int wx0 = 0;
+    bool row_in = false;
+    // (with them this lane's part in the sums and in the tabled 4x4 inverse, dsm_math.h kInv4: tables in memory too)
+    int d2[4] = {0, 0, 0, 0}, oe[7] = {0, 0, 0, 0, 0, 0, 1};
+    if (gl < 12)
+#pragma unroll
+        for (int q = 0; q < 4; q++) d2[q] = kInv4.det2[gl][q];
+#pragma unroll
+    for (int q = 0; q < 7; q++) oe[q] = kInv4.out[gl][q];
+    const int xcol = kFitX[gl], ycol = kFitY[gl], h_row = kFitRow[gl], h_col = kFitColI[gl];
     if (live) {
         hd = c->gn_hdr[s];
         core = c->core[s];
+        const float *dep = frame_depth(c, fp);
+        const int w = c->w, h = c->h, pitch = c->pitch;
+        int gx, gy;
+        seed_cell(c, s, gx, gy);
+        wx0 = gx * kCell + kCell / 2 - kCell;
+        const int y = gy * kCell + kCell / 2 - kCell + gl;
+        row_in = (unsigned)y < (unsigned)h;
+        const unsigned row = (unsigned)__mul24(y < 0 ? 0 : (y > h - 1 ? h - 1 : y), pitch);
+        row_ry = ld_off(c->ray_y, (unsigned)(y < 0 ? 0 : (y > h ? h : y)) << 2);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { // window quads redirected into the row where they leave it (masked below)
+            const int xq = wx0 + 4 * q;
+            const unsigned o4 = (row + (unsigned)(xq < 0 ? 0 : (xq > pitch - 4 ? pitch - 4 : xq))) << 2;
+            row_lab[q] = ld_vec<int4>(c->label, o4);
+            row_dp[q] = ld_vec<float4>(dep, o4);
+        }
+#pragma unroll
+        for (int j = 0; j < kWin; j++) {
+            const int x = wx0 + j;
+            row_rx[j] = ld_off(c->ray_x, (unsigned)(x < 0 ? 0 : (x > w ? w : x)) << 2);
+        }
     }
     const int m = hd.m_in;
     int mg[kFitSeeds];
@@ -1630,29 +1668,13 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
         }
         wave_lds_sync();
         if (m > 0) {
-            const float *dep = frame_depth(c, fp);
-            const int w = c->w, h = c->h, pitch = c->pitch;
-            int gx, gy;
-            seed_cell(c, s, gx, gy);
-            const int wx0 = gx * kCell + kCell / 2 - kCell, y = gy * kCell + kCell / 2 - kCell + gl;
-            const bool row_in = (unsigned)y < (unsigned)h;
-            const unsigned row = (unsigned)__mul24(y < 0 ? 0 : (y > h - 1 ? h - 1 : y), pitch);
-            const float ry = ld_off(c->ray_y, (unsigned)(y < 0 ? 0 : (y > h ? h : y)) << 2);
-            int4 lab[4];
-            float4 dp[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { // window quads redirected into the row where they leave it (masked below)
-                const int xq = wx0 + 4 * q;
-                const unsigned o4 = (row + (unsigned)(xq < 0 ? 0 : (xq > pitch - 4 ? pitch - 4 : xq))) << 2;
-                lab[q] = ld_vec<int4>(c->label, o4);
-                dp[q] = ld_vec<float4>(dep, o4);
-            }
+            const int w = c->w;
             const float md = core.w;
             unsigned inl = 0; // this row's inliers, bit j = window column j
 #pragma unroll
             for (int j = 0; j < kWin; j++) {
-                const float d = comp(dp[j >> 2], j & 3);
-                const bool ok = row_in && (unsigned)(wx0 + j) < (unsigned)w && comp(lab[j >> 2], j & 3) == s && d > flt_below(0.05) &&
+                const float d = comp(row_dp[j >> 2], j & 3);
+                const bool ok = row_in && (unsigned)(wx0 + j) < (unsigned)w && comp(row_lab[j >> 2], j & 3) == s && d > flt_below(0.05) &&
                                 fabsf(md - d) < hr_above;
                 inl |= ok ? 1u << j : 0u;
             }
@@ -1666,25 +1688,16 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
             int pos = pre - cnt;
 #pragma unroll
             for (int j = 0; j < kWin; j++) {
-                if ((inl >> j) & 1u) {
-                    const float d = comp(dp[j >> 2], j & 3);
-                    const int xc = wx0 + j; // in [0, w) for an inlier
-                    s_col[g][0][pos] = ld_off(c->ray_x, (unsigned)xc << 2) * d - hd.mx;
-                    s_col[g][1][pos] = ry * d - hd.my;
+                if ((inl >> j) & 1u) { // (column wx0 + j is in [0, w) for an inlier: its ray is the unclamped one)
+                    const float d = comp(row_dp[j >> 2], j & 3);
+                    s_col[g][0][pos] = row_rx[j] * d - hd.mx;
+                    s_col[g][1][pos] = row_ry * d - hd.my;
                     s_col[g][2][pos] = d - hd.mz;
                     pos++;
                 }
             }
         }
-        // per-lane rows of the tabled 4x4 inverse (dsm_math.h, kInv4)
-        int d2[4] = {0, 0, 0, 0}, oe[7] = {0, 0, 0, 0, 0, 0, 1};
-        if (gl < 12)
-#pragma unroll
-            for (int q = 0; q < 4; q++) d2[q] = kInv4.det2[gl][q];
-#pragma unroll
-        for (int q = 0; q < 7; q++) oe[q] = kInv4.out[gl][q];
         double *SA = s_solver[g], *SD = SA + 16, *SO = SA + 28, *SJ = SA + 44, *SU = SA + 48;
-        const int xcol = kFitX[gl], ycol = kFitY[gl], h_row = kFitRow[gl], h_col = kFitColI[gl];
         const bool is_j = gl >= 10 && gl < 14;
         const float *xc = xcol == 4 ? s_ones : s_col[g][xcol], *yc = ycol == 4 ? s_ones : s_col[g][ycol];
         const int xs = xcol == 4 ? 0 : 1, ys = ycol == 4 ? 0 : 1;
