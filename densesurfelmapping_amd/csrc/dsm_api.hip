@@ -755,7 +755,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     // (size mod 8) > 4 (KITTI's 1242x375, 1238x374) leaves border pixels with no candidate seed: they are labelled
     // -1 and belong to no superpixel (dsm_math.h, has_candidate_cell) -- the reference runs these sizes the same
     // way, through reads and writes of superpixel_seeds[-1] that happen to be harmless (FF.cpp:442-451).
-    if ((w / kCell) * (hh / kCell) > 64 * 1024) return fail(nullptr, DSM_E_INVALID, "more than 65536 superpixels");
+    if ((w / kCell) * (hh / kCell) > kMaxSeeds) return fail(nullptr, DSM_E_INVALID, "more than 65535 superpixels");
     if (!(cfg->fx != 0) || !(cfg->fy != 0)) return fail(nullptr, DSM_E_INVALID, "zero focal length");
     // the kernels compare floats against these double constants in fp32 (dsm_math.h, flt_above / flt_below): the
     // neighbouring-float construction holds for positive normal thresholds only
@@ -1474,14 +1474,22 @@ int dsm_last_new_count(dsm_handle *h, int32_t *n_new) {
 
 // ------------------------------------------------------------------ taps
 
+// The label plane is 16 bits per pixel on the device (label_t); the taps speak the reference's int.
+static int labels_to_host(dsm_handle *h, int32_t *out) {
+    const size_t w = (size_t)h->hc.w, n = w * (size_t)h->hc.h;
+    std::vector<label_t> tmp(n);
+    HIP_TRY(h, hipMemcpy2D(tmp.data(), w * sizeof(label_t), h->hc.label, (size_t)h->hc.pitch * sizeof(label_t), w * sizeof(label_t),
+                           (size_t)h->hc.h, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) out[i] = tmp[i] == kNoLabel ? -1 : (int32_t)tmp[i];
+    return DSM_OK;
+}
+
 int dsm_get_labels(dsm_handle *h, int32_t *out) {
     if (!h || !out) return DSM_E_INVALID;
     int rc = bind_device(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(out, (size_t)h->hc.w * 4, h->hc.label, (size_t)h->hc.pitch * 4, (size_t)h->hc.w * 4,
-                           (size_t)h->hc.h, hipMemcpyDeviceToHost));
-    return DSM_OK;
+    return labels_to_host(h, out);
 }
 
 int dsm_get_seeds(dsm_handle *h, dsm_seed *out) {
@@ -1514,9 +1522,7 @@ int dsm_debug_get_label_buffer(dsm_handle *h, int which, int32_t *out) {
     int rc = bind_device(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(out, (size_t)h->hc.w * 4, h->hc.label, (size_t)h->hc.pitch * 4,
-                           (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyDeviceToHost));
-    return DSM_OK;
+    return labels_to_host(h, out);
 }
 
 int dsm_debug_set_label_buffer(dsm_handle *h, int which, const int32_t *in) {
@@ -1532,9 +1538,12 @@ int dsm_debug_set_label_buffer(dsm_handle *h, int which, const int32_t *in) {
             if (l >= h->hc.n_seed || l < -1 || (l == -1) == reach)
                 return fail(h, DSM_E_INVALID, "label %d at (%d, %d) is not a superpixel index of this %d-seed grid", l, x, y, h->hc.n_seed);
         }
+    const size_t w = (size_t)h->hc.w, n = w * (size_t)h->hc.h;
+    std::vector<label_t> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = in[i] < 0 ? (label_t)kNoLabel : (label_t)in[i];
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(h->hc.label, (size_t)h->hc.pitch * 4, in, (size_t)h->hc.w * 4,
-                           (size_t)h->hc.w * 4, (size_t)h->hc.h, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy2D(h->hc.label, (size_t)h->hc.pitch * sizeof(label_t), tmp.data(), w * sizeof(label_t), w * sizeof(label_t),
+                           (size_t)h->hc.h, hipMemcpyHostToDevice));
     return DSM_OK;
 }
 

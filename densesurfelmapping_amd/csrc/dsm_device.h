@@ -9,6 +9,9 @@
 namespace dsm {
 
 constexpr int kIntMax = 0x7fffffff;
+typedef uint16_t label_t;             // a pixel's superpixel index in the label planes
+constexpr int kNoLabel = 0xffff;      // the reference's label -1 (pixels no cell reaches) in a label plane
+constexpr int kMaxSeeds = 0xffff;     // superpixels a frame can have (dsm_create checks): every index fits a label_t below kNoLabel
 
 // Per-frame inputs that change from frame to frame.  A ring of these lives in HBM; kernels pick
 // entry (cursor % ring) so a captured hipGraph can be replayed without touching its arguments.
@@ -59,8 +62,11 @@ struct DeviceCtx {
     int64_t slot_elems; // pitch * h
     int32_t n_slots;
     // superpixel state
-    int32_t *label; // [h][pitch] superpixel index of every pixel: every sweep's image in turn (k_apply_labels works in place), then the final one
-    int32_t *cand;  // [h][pitch] seed picked by this sweep before the stable-skip rule is applied
+    // 16 bits per pixel (label_t: a frame has at most kMaxSeeds = 65 535 superpixels, kNoLabel = the reference's -1): the label
+    // image is read by every stage of a frame, by the window walks several times over -- a third of a frame's memory-side
+    // traffic when it was 4 bytes per pixel
+    label_t *label; // [h][pitch] superpixel index of every pixel: every sweep's image in turn (k_apply_labels works in place), then the final one
+    label_t *cand;  // [h][pitch] seed picked by this sweep before the stable-skip rule is applied
     float4 *core;   // [S] x, y, mean_intensity, mean_depth  (live seed state during the sweeps)
     double *inv_depth; // [S] 1.0 / mean_depth, FF.cpp:380
     float4 *core_stage; // [S] update_seeds output before the chunk-commit rule

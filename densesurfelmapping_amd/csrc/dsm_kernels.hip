@@ -203,6 +203,18 @@ template <typename T> __device__ __forceinline__ T ld_vec(const void *base, unsi
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 __device__ __forceinline__ int comp(const int4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+// Label planes (label_t, 16 bits per pixel).  One pixel as the reference's int (-1 = no superpixel) / four pixels of a
+// row as they lie in memory, and pixel t of the four as its 16 bits (compared with a seed index as they are: kNoLabel
+// equals none, and "no seed" on the other side is a value above 16 bits).
+__device__ __forceinline__ int label_at(const label_t *plane, unsigned pixel) {
+    const int l = (int)ld_off(plane, pixel << 1);
+    return l == kNoLabel ? -1 : l;
+}
+__device__ __forceinline__ void label_put(label_t *plane, unsigned pixel, int l) { st_off(plane, pixel << 1, (label_t)l); } // (-1 -> kNoLabel)
+typedef uint2 LabelQuad;
+__device__ __forceinline__ LabelQuad label_quad(const label_t *plane, unsigned pixel) { return ld_vec<LabelQuad>(plane, pixel << 1); }
+__device__ __forceinline__ unsigned comp(const LabelQuad &v, int t) { return t == 0 ? v.x & 0xffffu : t == 1 ? v.x >> 16 : t == 2 ? v.y & 0xffffu : v.y >> 16; }
+constexpr int kNoSeed = 0x10000; // compared with 16 bits of a label plane: equals no label
 __device__ __forceinline__ float comp(const float4 &v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 // grid cell of seed s (s < 65 536: dsm_create): the quotient by multiplication with the reciprocal the host rounded up
 __device__ __forceinline__ void seed_cell(const DeviceCtx *c, int s, int &gx, int &gy) {
@@ -380,14 +392,14 @@ template <int COLS> struct AssignTile { // COLS pixels per thread: 4 in launches
 // by repeated atomicMin.  Every pixel whose seed was unstable applies its own atomicMin directly;
 // only pixels whose old and new seeds were both stable (a short list: borders between two seeds
 // that stopped moving) can still change the picture; k_resolve iterates that list to the fixed point.
-__device__ void resolve_worklist(const DeviceCtx *c, const int32_t *label_in) {
+__device__ void resolve_worklist(const DeviceCtx *c, const label_t *label_in) {
     const int n = c->work_count[0];
     if (n == 0) return;
     for (;;) {
         int changed = 0;
         for (int i = threadIdx.x; i < n; i += 256) {
             const int p = c->worklist[i];
-            const int l = label_in[p], pk = c->cand[p];
+            const int l = label_in[p], pk = c->cand[p]; // (both seeds of a listed pixel exist)
             if (load_coherent(&c->tmin[l]) < p && load_coherent(&c->tmin[pk]) > p) {
                 atomicMin(&c->tmin[pk], p);
                 changed = 1;
@@ -409,7 +421,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *label_in = c->label; // the previous sweep's image (sweep >= 1)
+    const label_t *label_in = c->label; // the previous sweep's image (sweep >= 1)
     const int w = c->w, h = c->h, pitch = c->pitch, gw = c->gw, gh = c->gh;
     const int bx = blk.x * kTileW, by = blk.y * kTileH;
     const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
@@ -435,7 +447,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         const unsigned p = y0 + r < h ? p0 + (unsigned)(r * pitch) : p0, p4 = p << 2; // byte offsets into the 4-byte planes, see ld_off
         pix_i[r] = (float)ld_off(img, p);
         pix_d[r] = ld_off(dep, p4);
-        lab[r] = FIRST ? 0 : ld_off(label_in, p4);
+        lab[r] = FIRST ? 0 : label_at(label_in, p);
     }
     const PickQuad quad = pick_quad(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &inv_f) {
         const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
@@ -448,11 +460,10 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         const int y = y0 + r;
         if (y >= h) break;
         const int p = (int)p0 + r * pitch;
-        const unsigned p4 = (unsigned)p << 2;
         if (!has_candidate_cell(x, y, gw, gh)) {
             // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
             // every seed window ends before them, and k_apply_labels keeps a -1)
-            if (FIRST) c->label[p] = -1;
+            if (FIRST) label_put(c->label, (unsigned)p, -1);
             continue;
         }
         // the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast); the few
@@ -470,11 +481,11 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         const int l = lab[r];
         if (pick < 0) { // every candidate cost >= the reference's 1e6 sentinel: it would index seeds[-1]
             atomicOr(c->status, kStatusBadPick);
-            if (FIRST) st_off(c->label, p4, 0); else st_off(c->cand, p4, l);
+            if (FIRST) label_put(c->label, (unsigned)p, 0); else label_put(c->cand, (unsigned)p, l);
         } else if (FIRST) {
-            st_off(c->label, p4, pick);
+            label_put(c->label, (unsigned)p, pick);
         } else {
-            st_off(c->cand, p4, pick);
+            label_put(c->cand, (unsigned)p, pick);
             const int tl = ld_off(c->tmin, (unsigned)l << 2); // -1 never changes; >= 0 only moves among values >= 0
             if (tl == -1) {
                 // the old seed was unstable at sweep start: this pixel is evaluated whatever happens
@@ -626,7 +637,7 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *lbl = c->label;
+    const label_t *lbl = c->label;
     const int w = c->w, h = c->h, pitch = c->pitch;
     int gx, gy;
     seed_cell(c, s, gx, gy);
@@ -650,7 +661,7 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
         pimg[k] = x_in && y >= 0 && y < h;
         const int pk = pimg[k] ? key0 + k * row4 : 0;
         const unsigned o4 = (unsigned)pk << 2;
-        lab[k] = ld_off(lbl, o4);
+        lab[k] = (int)ld_off(lbl, (unsigned)pk << 1); // (16 bits: kNoLabel equals no seed)
         pd[k] = ld_off(dep, o4);
         pi[k] = (int)ld_off(img, (unsigned)pk);
     }
@@ -689,19 +700,21 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_apply_labels(cons
     const int xq = blk.x * 64 + (threadIdx.x & 63), y = blk.y * 4 + (threadIdx.x >> 6);
     if (4 * xq >= pitch || y >= c->h) return;
     const int key0 = __mul24(y, pitch) + 4 * xq;
-    const unsigned o4 = (unsigned)key0 << 2;
-    const int4 lab = ld_vec<int4>(c->label, o4), cd = ld_vec<int4>(c->cand, o4);
-    const int l[4] = {lab.x, lab.y, lab.z, lab.w}, pk[4] = {cd.x, cd.y, cd.z, cd.w};
-    int t[4], o[4];
+    const LabelQuad lab = label_quad(c->label, (unsigned)key0), cd = label_quad(c->cand, (unsigned)key0);
+    unsigned l[4], o[4];
+    int t[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) t[j] = l[j] >= 0 ? ld_off(c->tmin, (unsigned)l[j] << 2) : kIntMax;
+    for (int j = 0; j < 4; j++) {
+        l[j] = comp(lab, j);
+        t[j] = l[j] != (unsigned)kNoLabel ? ld_off(c->tmin, l[j] << 2) : kIntMax;
+    }
     bool changed = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        o[j] = t[j] < key0 + j ? pk[j] : l[j];
+        o[j] = t[j] < key0 + j ? comp(cd, j) : l[j];
         changed = changed || o[j] != l[j];
     }
-    if (changed) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(c->label) + o4) = make_int4(o[0], o[1], o[2], o[3]);
+    if (changed) *reinterpret_cast<LabelQuad *>(reinterpret_cast<char *>(c->label) + ((unsigned)key0 << 1)) = make_uint2(o[0] | o[1] << 16, o[2] | o[3] << 16);
 }
 
 // One Huber-Newton pass (FF.cpp:536-553) of up to 64 seeds at once, one chain per lane: a = ordered sum of 2*r over the
@@ -797,7 +810,7 @@ __device__ __forceinline__ int32_t *queue_wave(const DeviceCtx *c) { return c->w
 __device__ __forceinline__ int32_t *fit_order(const DeviceCtx *c) { return c->worklist + 4 * c->n_seed; }
 
 struct LaneRow { // one window row of one lane: 16 labels, depths, intensities
-    int4 lab[4];
+    LabelQuad lab[4];
     float4 dp[4];
     unsigned im[4];
 };
@@ -814,7 +827,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
-    const int32_t *lbl = c->label;
+    const label_t *lbl = c->label;
     const int w = c->w, h = c->h, pitch = c->pitch;
     // bottom rows first, see seed_of_block
     const int s = (((S + 63) >> 6) - 1 - blk.x) * 64 + lane;
@@ -826,8 +839,8 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     const int t_self = c->tmin[sc];
     const float4 old = c->core[sc];
     const bool stats = live && t_self != kIntMax; // stable seeds keep their state: FF.cpp:479-480
-    const int s_match = stats ? s : -2;           // no label is -2
-    // the four 16-byte quads of a window row, as pixel offsets within the row; a quad wholly outside the row (x < 0 at
+    const unsigned s_match = stats ? (unsigned)s : (unsigned)kNoSeed;
+    // the four quads of a window row, as pixel offsets within the row; a quad wholly outside the row (x < 0 at
     // the left border, x >= pitch where the pitch equals the width) is redirected to an in-range one and masked below
     int qx[4];
 #pragma unroll
@@ -837,9 +850,9 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     }
     // statistics window clipped to [0, w-1) x [0, h-1): the last row and column never contribute.  What a label of window
     // column j is compared with: the seed, or no label at all where the column is outside
-    int s_col[kWin];
+    unsigned s_col[kWin];
 #pragma unroll
-    for (int j = 0; j < kWin; j++) s_col[j] = (unsigned)(wx0 + j) < (unsigned)(w - 1) ? s_match : -2;
+    for (int j = 0; j < kWin; j++) s_col[j] = (unsigned)(wx0 + j) < (unsigned)(w - 1) ? s_match : (unsigned)kNoSeed;
 
     auto load_row = [&](int r) {
         LaneRow R;
@@ -849,7 +862,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const unsigned o = row + (unsigned)qx[q], o4 = o << 2;
-            R.lab[q] = ld_vec<int4>(lbl, o4);
+            R.lab[q] = label_quad(lbl, o);
             R.dp[q] = ld_vec<float4>(dep, o4);
             R.im[q] = ld_vec<unsigned>(img, o);
         }
@@ -1149,7 +1162,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
         const int y = y0 + 4 * k;
         const bool in = x0 >= 0 && x0 < w && y >= 0 && y < h;
         const unsigned o4 = in ? (unsigned)(key0 + k * row4) << 2 : 0u;
-        const int l = ld_off(c->label, o4);
+        const int l = (int)ld_off(c->label, o4 >> 1); // (16 bits: kNoLabel equals no seed)
         lab[k] = in ? l : -1;
         pd[k] = ld_off(dep, o4);
     }
@@ -1266,7 +1279,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(con
     if (x >= w || y >= h) return;
     const unsigned p = (unsigned)(__mul24(y, pitch) + x), p4 = p << 2;
     const float d = ld_off(dep, p4);
-    const int l = ld_off(c->label, p4);
+    const int l = label_at(c->label, p);
     // only the depth inliers of their own superpixel are ever read (k_seed_stats asks for exactly those): nothing is
     // stored for any other pixel; an inlier on the image border has no normal (FF.cpp:670-677) and stores zeros
     if (!(l >= 0 && d > flt_below(0.05))) return;                      // (double)d > 0.05
@@ -1294,7 +1307,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(con
 // unchanged, bit for bit).  The wave-per-seed form spent 611 VALU instructions per seed on this, most of them per-seed
 // bookkeeping and six-lane sums; a lane spends ~26 per window pixel for 64 seeds at once.
 struct StatRow { // one window row of one lane: labels and depths
-    int4 lab[4];
+    LabelQuad lab[4];
     float4 dp[4];
 };
 template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
@@ -1319,7 +1332,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
     const float4 core = c->core[sc];
     const float md = core.w;
     const float hr_above = flt_above(c->huber); // the Huber class tests in fp32 (dsm_math.h)
-    const int s_match = live ? s : -2;          // no label is -2
+    const unsigned s_match = live ? (unsigned)s : (unsigned)kNoSeed;
     s_inl[kWin][lane] = s_inl[kWin + 1][lane] = 0; // (the second walk's loop runs two rows past the window)
     int qx[4];                                  // window quads as pixel offsets within a row, redirected into the row (see k_update_seeds)
 #pragma unroll
@@ -1352,7 +1365,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const unsigned o4 = (row + (unsigned)qx[q]) << 2;
-            R.lab[q] = ld_vec<int4>(c->label, o4);
+            R.lab[q] = label_quad(c->label, o4 >> 2);
             R.dp[q] = ld_vec<float4>(dep, o4);
         }
         return R;
@@ -1360,7 +1373,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_seed_stats(const D
     auto walk_a = [&](const StatRow &A, int r) {
         const int y = wy0 + r;
         const bool row_in = (unsigned)y < (unsigned)h;
-        const int s_row = row_in ? s_match : -2;
+        const unsigned s_row = row_in ? s_match : (unsigned)kNoSeed;
         const int yc = y < 0 ? 0 : (y > h ? h : y);
         const float ry = ld_off(c->ray_y, (unsigned)yc << 2);
         const float ey = (float)y - core.y, eyy = ey * ey;
@@ -1600,7 +1613,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
     // this lane's window row (labels, depths, the rays of the sixteen columns) for the gather below -- whether the seed has
     // a list at all is in the header, but a wave of this kernel lives as long as its round trips take (a third of a
     // wave's life was waiting: for the header, then for the rows, then for one ray per inlier column, each in turn).
-    int4 row_lab[4];
+    LabelQuad row_lab[4];
     float4 row_dp[4];
     float row_rx[kWin], row_ry = 0.0f;
     int wx0 = 0;
@@ -1629,7 +1642,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
         for (int q = 0; q < 4; q++) { // window quads redirected into the row where they leave it (masked below)
             const int xq = wx0 + 4 * q;
             const unsigned o4 = (row + (unsigned)(xq < 0 ? 0 : (xq > pitch - 4 ? pitch - 4 : xq))) << 2;
-            row_lab[q] = ld_vec<int4>(c->label, o4);
+            row_lab[q] = label_quad(c->label, o4 >> 2);
             row_dp[q] = ld_vec<float4>(dep, o4);
         }
 #pragma unroll
@@ -1674,7 +1687,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
 #pragma unroll
             for (int j = 0; j < kWin; j++) {
                 const float d = comp(row_dp[j >> 2], j & 3);
-                const bool ok = row_in && (unsigned)(wx0 + j) < (unsigned)w && comp(row_lab[j >> 2], j & 3) == s && d > flt_below(0.05) &&
+                const bool ok = row_in && (unsigned)(wx0 + j) < (unsigned)w && comp(row_lab[j >> 2], j & 3) == (unsigned)s && d > flt_below(0.05) &&
                                 fabsf(md - d) < hr_above;
                 inl |= ok ? 1u << j : 0u;
             }
@@ -2014,7 +2027,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
             FuseOutcome oc = fuse_project(fc, ref_idx, inv, e, ui, vi, pc, nc);
             if (oc == kFuseNeedPixel) {
                 const unsigned p4 = (unsigned)(__mul24(vi, c->pitch) + ui) << 2; // byte offsets, see ld_off
-                const int sidx = ld_off(c->label, p4);
+                const int sidx = label_at(c->label, p4 >> 2);
                 const float pix_depth = ld_off(dep, p4);
                 SeedView sd = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // label -1 (ragged border): the all-zero seed, see has_candidate_cell
                 float w1 = 0.0f;

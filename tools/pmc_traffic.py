@@ -6,7 +6,8 @@
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters come out in KB; on gfx950
 FETCH_SIZE under-reports reads by a width-dependent factor and has to be calibrated on a kernel whose read bytes are
 known in the same access pattern.  Calibration kernel: k_assign<true> reads exactly the image (1 B/pixel) and depth
-(4 B/pixel) planes and writes the label plane (4 B/pixel); the factors found are recorded in the output.
+(4 B/pixel) planes and writes the label plane (2 B/pixel since round 4's 16-bit labels); the factors found are recorded
+in the output.
 """
 import csv
 import glob
@@ -62,11 +63,11 @@ def main():
     cal_name = "k_assign<true, true, 4>" if nb > 1 else "k_assign<true>"
     n *= nb
     cal_f = (5 * n / 1024.0) / fetch[cal_name]
-    cal_w = (4 * n / 1024.0) / write[cal_name]
+    cal_w = (2 * n / 1024.0) / write[cal_name]
     out = {"source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `{cmd}` (tools/gpu_pmc.sh), 1226x370",
            "units": "FETCH_SIZE / WRITE_SIZE are reported in KB",
            "subsequences_per_launch": nb,
-           "calibration": {"kernel": cal_name, "known_read_bytes": 5 * n, "known_write_bytes": 4 * n,
+           "calibration": {"kernel": cal_name, "known_read_bytes": 5 * n, "known_write_bytes": 2 * n,
                            "fetch_factor_found": round(cal_f, 3), "write_factor_found": round(cal_w, 3),
                            "applied": "FETCH_SIZE x fetch_factor_found; WRITE_SIZE as reported when its factor is within 5 % of 1"},
            "kernels": {}}
