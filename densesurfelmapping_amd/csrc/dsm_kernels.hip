@@ -683,7 +683,7 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
     update_seed_finish(c, sweep, s, lane, wx0, wy0, old, dl, lt, cnt, sdx, sdy, si, nd);
 }
 
-// ---- the label image of a sweep >= 1, one thread per four pixels of a row:  new(p) = T[old(p)] < p ? pick(p) : old(p)
+// ---- the label image of a sweep >= 1, one thread per eight pixels of a row (16 bytes of each plane):  new(p) = T[old(p)] < p ? pick(p) : old(p)
 // with T = tmin after k_resolve (see k_assign), IN PLACE: a pixel's new label needs nothing but its own old one, and most
 // pixels keep theirs -- only quads in which a label changes are stored.  Until round 4 every seed's window walk formed
 // the new labels on the fly for the 256 pixels of its window -- every pixel four times over, each time behind a gather of
@@ -698,23 +698,27 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_apply_labels(cons
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     const int pitch = c->pitch;
     const int xq = blk.x * 64 + (threadIdx.x & 63), y = blk.y * 4 + (threadIdx.x >> 6);
-    if (4 * xq >= pitch || y >= c->h) return;
-    const int key0 = __mul24(y, pitch) + 4 * xq;
-    const LabelQuad lab = label_quad(c->label, (unsigned)key0), cd = label_quad(c->cand, (unsigned)key0);
-    unsigned l[4], o[4];
-    int t[4];
+    if (8 * xq >= pitch || y >= c->h) return;
+    const int key0 = __mul24(y, pitch) + 8 * xq;
+    const uint4 lab = ld_vec<uint4>(c->label, (unsigned)key0 << 1), cd = ld_vec<uint4>(c->cand, (unsigned)key0 << 1);
+    const unsigned lw[4] = {lab.x, lab.y, lab.z, lab.w}, cw[4] = {cd.x, cd.y, cd.z, cd.w};
+    unsigned l[8], o[8];
+    int t[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        l[j] = comp(lab, j);
+    for (int j = 0; j < 8; j++) {
+        l[j] = (j & 1) ? lw[j >> 1] >> 16 : lw[j >> 1] & 0xffffu;
         t[j] = l[j] != (unsigned)kNoLabel ? ld_off(c->tmin, l[j] << 2) : kIntMax;
     }
     bool changed = false;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        o[j] = t[j] < key0 + j ? comp(cd, j) : l[j];
+    for (int j = 0; j < 8; j++) {
+        const unsigned pk = (j & 1) ? cw[j >> 1] >> 16 : cw[j >> 1] & 0xffffu;
+        o[j] = t[j] < key0 + j ? pk : l[j];
         changed = changed || o[j] != l[j];
     }
-    if (changed) *reinterpret_cast<LabelQuad *>(reinterpret_cast<char *>(c->label) + ((unsigned)key0 << 1)) = make_uint2(o[0] | o[1] << 16, o[2] | o[3] << 16);
+    if (changed)
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(c->label) + ((unsigned)key0 << 1)) =
+            make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
 }
 
 // One Huber-Newton pass (FF.cpp:536-553) of up to 64 seeds at once, one chain per lane: a = ordered sum of 2*r over the
@@ -2704,7 +2708,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
     const dim3 g_tile1((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<1>::kH - 1) / AssignTile<1>::kH);
     const dim3 g_tile4((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<4>::kH - 1) / AssignTile<4>::kH);
     const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
-    const dim3 g_quad4((hc.pitch / 4 + 63) / 64, (hc.h + 3) / 4); // thread per four pixels of a row, 256 x 4 per block
+    const dim3 g_row8((hc.pitch / 8 + 63) / 64, (hc.h + 3) / 4); // thread per eight pixels of a row, 512 x 4 per block
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
     if (lanes) hipLaunchStage(k_init_seeds_lanes<true>, k_init_seeds_lanes<true>, g_seed_thr, dim3(256));
@@ -2720,7 +2724,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
             else hipLaunchStage((k_assign<false, false, 1>), (k_assign<false, true, 1>), g_tile1, dim3(256), sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
-            hipLaunchStage(k_apply_labels<false>, k_apply_labels<true>, g_quad4, dim3(256), sweep); // (part of the resolve stage: the sweep's label image)
+            hipLaunchStage(k_apply_labels<false>, k_apply_labels<true>, g_row8, dim3(256), sweep); // (part of the resolve stage: the sweep's label image)
             DSM_MARK();
         }
         if (lanes) {
