@@ -115,6 +115,8 @@ typedef struct dsm_handle dsm_handle;
 int dsm_config_init(dsm_config *cfg, int width, int height, float fx, float fy, float cx, float cy,
                     float far_dist, float near_dist, int rgbd);
 
+/* (width / 8) * (height / 8) <= 65 535 superpixels per frame (DSM_E_INVALID beyond: 4K frames are out of range, 1920x1080
+ * has 32 400): superpixel indices are 16 bits in the device's label planes; the taps below speak int32, -1 = no superpixel. */
 int dsm_create(const dsm_config *cfg, dsm_handle **out);
 void dsm_destroy(dsm_handle *h);
 const char *dsm_last_error(const dsm_handle *h); /* h may be NULL: last dsm_create error */
