@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libdsm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["dsm_kernels.hip", "dsm_api.hip", "dsm_surfel_map.cpp"]
-HEADERS = ["dsm_math.h", "dsm_device.h", os.path.join("..", "..", "include", "dsm.h"),
+HEADERS = ["dsm_math.h", "dsm_device.h", "dsm_k_common.h", "dsm_k_superpixel.h", "dsm_k_planes.h", "dsm_k_map.h", os.path.join("..", "..", "include", "dsm.h"),
            os.path.join("..", "..", "include", "dsm_surfel_map.h")]
 
 

@@ -166,7 +166,7 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
     assert pixels >= frames * 3 * cam.width * cam.height * 0.9 and checked > pixels
     assert mismatches == 0 and violations == 0, (mismatches, violations)
     assert unsure < 0.02 * pixels, (unsure, pixels)
-    # the exact-sum claim behind k_seed_fit's tree-ordered Jacobian sums (dsm_kernels.hip, row16_sum): fp32-product terms
+    # the exact-sum claim behind k_seed_fit's tree-ordered Jacobian sums (tools/_exp/r04_fit_tree.patch, row16_sum): fp32-product terms
     # spanning <= 21 binades sum exactly in double in ANY order -- on every qualifying sum of every fitted seed a 16-way
     # tree gives the ordered sum's bits, and nearly every all-core step qualifies
     ex = (C.c_longlong * 6)()

@@ -190,6 +190,9 @@ def test_api_errors_are_reported(mods):
     with pytest.raises(api.DsmError) as ei:  # fewer than 3x3 superpixel cells
         api.FusionFunctions().initialize(20, 96, 100, 100, 80, 48, 30, 0.5)
     assert ei.value.code == -1
+    with pytest.raises(api.DsmError) as ei:  # 3840x2160: 129 600 superpixels do not fit the 16-bit label planes
+        api.FusionFunctions().initialize(3840, 2160, 2000, 2000, 1920, 1080, 30, 0.5)
+    assert ei.value.code == -1 and "65535 superpixels" in str(ei.value)
     ff = api.FusionFunctions.from_camera(cam, surfel_capacity=128, frame_slots=2)
     img, dep, pose = synth.render(cam, synth.Scene(), 0)
     with pytest.raises(api.DsmError) as ei:  # resident call before a map exists
