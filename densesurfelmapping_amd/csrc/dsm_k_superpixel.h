@@ -84,7 +84,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds(const 
 // handle, each a chain of three dependent trips to memory (cursor -> params -> pixels) that ends in one 16-byte store per
 // sixteen lanes -- 56 000 workgroups per launch of 128 handles, 153 us of wave turnover.  Here a lane reads its seed's
 // centre pixel, and only a wave that holds a seed without depth there walks windows: every such lane its own, row by row
-// from the last to the first so that the lowest row and column with a depth is what remains (FF.cpp:600-626).
+// from the first until it has found the lowest row and column with a depth (FF.cpp:600-626).
 template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds_lanes(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
@@ -123,29 +123,40 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_init_seeds_lanes(
         const int wx0 = gx * kCell + kCell / 2 - kCell, wy0 = gy * kCell + kCell / 2 - kCell;
         const int x_lo = wx0 < 0 ? 0 : wx0, x_hi = wx0 + 2 * kCell > w - 1 ? w - 1 : wx0 + 2 * kCell;
         const int y_lo = wy0 < 0 ? 0 : wy0, y_hi = wy0 + 2 * kCell > h - 1 ? h - 1 : wy0 + 2 * kCell;
-        bool hit = false;
-        float first = 0.0f;
-#pragma unroll 4
-        for (int r = 2 * kCell - 1; r >= 0; r--) {
-            const int y = wy0 + r;
-            const bool row_in = need && y >= y_lo && y < y_hi;
-            float4 v[4];
+        // rows from the first on, two at a time, until every lane that looks has found its pixel: the first hit in row-major
+        // order (a row is scanned from its last column down, so that its first hit remains).  Most seeds without a depth
+        // at their centre find one in the first rows; only a wave that holds an empty window (sky) walks all sixteen.
+        bool pending = need;
+#pragma unroll 1
+        for (int r0 = 0; r0 < 2 * kCell && __ballot(pending) != 0; r0 += 2) {
+            float4 v[2][4];
+            bool row_in[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int x = wx0 + 4 * q; // multiple of 4: 16-byte aligned, and never straddles x = 0
-                v[q] = (row_in && x >= 0) ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
-            }
+            for (int k = 0; k < 2; k++) {
+                const int y = wy0 + r0 + k;
+                row_in[k] = pending && y >= y_lo && y < y_hi;
 #pragma unroll
-            for (int q = 3; q >= 0; q--) {
-                const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-                for (int t = 3; t >= 0; t--) {
-                    const int x = wx0 + 4 * q + t;
-                    if (row_in && x >= x_lo && x < x_hi && e[t] > flt_below(0.01)) { hit = true; first = e[t]; }
+                for (int q = 0; q < 4; q++) {
+                    const int x = wx0 + 4 * q; // multiple of 4: 16-byte aligned, and never straddles x = 0
+                    v[k][q] = (row_in[k] && x >= 0) ? *reinterpret_cast<const float4 *>(dep + y * pitch + x) : make_float4(0, 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                bool hit = false;
+                float first = 0.0f;
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+                    const float e[4] = {v[k][q].x, v[k][q].y, v[k][q].z, v[k][q].w};
+#pragma unroll
+                    for (int t = 3; t >= 0; t--) {
+                        const int x = wx0 + 4 * q + t;
+                        if (row_in[k] && x >= x_lo && x < x_hi && e[t] > flt_below(0.01)) { hit = true; first = e[t]; }
+                    }
+                }
+                if (pending && hit) { md = first; pending = false; }
+            }
         }
-        if (need && hit) md = first;
     }
     if (!live) return;
     c->core[s] = make_float4((float)ix, (float)iy, mi, md);
