@@ -583,7 +583,7 @@ __device__ __forceinline__ float huber_pass_regs(const float (&v)[kRestRegs], in
 // ordered depth sum in registers, compacts its member depths in order into its own LDS row ([element][lane]:
 // conflict-free whatever the lanes' list lengths), and runs the first Huber-Newton pass as 64 independent chains: one
 // v_add serves 64 seeds.  Same operations on the same operands in the same order as the reference, seed by seed.  The
-// label image it reads is the sweep's own (k_apply_labels): 193 registers, two waves per SIMD where the form that
+// label image it reads is the sweep's own (k_apply_labels): 170 registers, two waves per SIMD where the form that
 // applied the labels inside the walk (round 3: two more row planes, a gathered tmin per pixel) held one.
 // What the first Huber pass does not finish goes to k_update_seeds_rest through two queues: the 13 % of the seeds that
 // need more passes, packed 64 to a wave again, and the seeds whose list does not fit the 123 depths a lane keeps in LDS (a
