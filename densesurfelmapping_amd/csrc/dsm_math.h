@@ -153,21 +153,35 @@ constexpr int kPickUnsure = -2;
 struct FastCost {
     float c, err;
 };
-DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float seed_inv_f, bool with_depth, float pix_i, float pix_invd, int x, int y) {
-    const float u = 5.9604645e-8f; // 2^-24
+constexpr float kFastU = 5.9604645e-8f; // u = 2^-24
+// the depth term's share of the bound, 800 e (2 |dd| + e) with e = u (|Df| + 3 |dd|), rounded up to e800 (2 |dd| + e800),
+// e800 = 800 e: one operation less.  df800 = 800 u |Df|.  Monotone in both arguments (every operand is >= 0 and rounding is
+// monotone): evaluated at the largest |dd| and the largest |Df| of several candidates it bounds every one of them.
+DSM_HD float fast_cost_slack(float ad, float df800) {
+    const float e800 = __builtin_fmaf(2400.0f * kFastU, ad, df800);
+    return e800 * __builtin_fmaf(2.0f, ad, e800);
+}
+// bound on |cost~ - cost| (20u: 4u of it for the candidate tag of pick_seed_fast); monotone in c and in the slack
+DSM_HD float fast_cost_err(float c, float slack) { return __builtin_fmaf(20.0f * kFastU, c, slack); }
+// the cost itself; ad = |dd| of the depth term (whether or not it applies)
+DSM_HD float pixel_cost_fast_value(float sx, float sy, float si, float seed_inv_f, bool with_depth, float pix_i, float pix_invd, int x, int y, float &ad) {
     const float ddx = sx - (float)x, ddy = sy - (float)y;
     const float dist = __builtin_fmaf(ddy, ddy, ddx * ddx);
     const float di = si - pix_i;
     const float c_no = __builtin_fmaf(dist, 0.0625f, (di * di) * 0.01f);
     // (no branches: every lane of a wave is another pixel, and the selects cost less than the exec-mask bookkeeping)
-    const float dd = seed_inv_f - pix_invd, ad = fabsf(dd);
+    const float dd = seed_inv_f - pix_invd;
+    ad = fabsf(dd);
     const float c_with = __builtin_fmaf(dd * dd, 400.0f, c_no);
-    // 800 e (2 |dd| + e) with e = u (|Df| + 3 |dd|), rounded up to e800 (2 |dd| + e800), e800 = 800 e: one operation less
-    const float e800 = __builtin_fmaf(2400.0f * u, ad, (800.0f * u) * fabsf(seed_inv_f));
-    const float slack = e800 * __builtin_fmaf(2.0f, ad, e800);
+    return with_depth ? c_with : c_no;
+}
+// one candidate with its own bound: what the proof above is about, and what tests/hostemu.cpp checks against the
+// reference's costs on every candidate
+DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float seed_inv_f, bool with_depth, float pix_i, float pix_invd, int x, int y) {
     FastCost r;
-    r.c = with_depth ? c_with : c_no;
-    r.err = __builtin_fmaf(20.0f * u, r.c, with_depth ? slack : 0.0f); // (20u: 4u of it for the candidate tag below)
+    float ad;
+    r.c = pixel_cost_fast_value(sx, sy, si, seed_inv_f, with_depth, pix_i, pix_invd, x, y, ad);
+    r.err = fast_cost_err(r.c, with_depth ? fast_cost_slack(ad, (800.0f * kFastU) * fabsf(seed_inv_f)) : 0.0f);
     return r;
 }
 // The candidates of a pixel are those of its 4 x 4 quadrant of a cell (see pick_seed): PickQuad holds them for all pixels
@@ -178,6 +192,7 @@ struct PickQuad {
     float sx[4], sy[4], si[4], sd[4], sinv[4]; // candidate k = (x offset k >> 1, y offset k & 1), the reference's scan order
     bool col_ok[2], row_in[2];                  // in the grid and, for columns, past the distance filter
     bool depth_ok[2];                           // [row offset]: both candidates of that row either out of play or with a mean depth
+    float df800_max;                            // 800 u max |sinv|, for the bound the four candidates share (fast_cost_slack)
     int gx0, gy0;
 };
 template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, int gh, LoadSeedF load) {
@@ -196,6 +211,7 @@ template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, in
         gy = gy < 0 ? 0 : (gy > gh - 1 ? gh - 1 : gy);
         load(gx, gy, q.sx[k], q.sy[k], q.si[k], q.sd[k], q.sinv[k]);
     }
+    q.df800_max = (800.0f * kFastU) * fmaxf(fmaxf(fabsf(q.sinv[0]), fabsf(q.sinv[1])), fmaxf(fabsf(q.sinv[2]), fabsf(q.sinv[3])));
     for (int j = 0; j < 2; j++)
         q.depth_ok[j] = !q.row_in[j] | ((!q.col_ok[0] | (q.sd[j] > 0)) & (!q.col_ok[1] | (q.sd[2 + j] > 0))); // (no short cuts: lane masks)
     return q;
@@ -213,15 +229,22 @@ DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pi
     // into the two lowest bits (a change of < 4 ulp, inside the error bound): the smallest tagged cost names the winner.
     // It is the reference's pick for sure if even the largest error bound of the four separates it from the runner-up
     // and from the sentinel the scan starts from.
+    // ONE bound for the four: the per-candidate bound (pixel_cost_fast) is monotone in the cost, in |dd| and in |Df|, so at
+    // the largest of each it holds for every candidate -- of a masked one too (its cell was clamped to a real one; the bound
+    // is merely larger).  The comparison below always used the largest of the four bounds; formed this way it costs 8
+    // instructions instead of 26 per pixel.
     uint32_t key[4];
-    float err_max = 0.0f;
+    float c_max = 0.0f, ad_max = 0.0f;
     for (int k = 0; k < 4; k++) {
-        const FastCost f = pixel_cost_fast(q.sx[k], q.sy[k], q.si[k], q.sinv[k], all_depth, pix_i, invd, x, y);
-        err_max = fmaxf(err_max, f.err); // (of a masked candidate too: its cell was clamped to a real one, the bound is merely larger)
-        const uint32_t bits = __builtin_bit_cast(uint32_t, f.c);
+        float ad;
+        const float ck = pixel_cost_fast_value(q.sx[k], q.sy[k], q.si[k], q.sinv[k], all_depth, pix_i, invd, x, y, ad);
+        c_max = fmaxf(c_max, ck); // (a NaN cost drops out of the maximum and, below, out of the candidates: it never wins the reference's '<' either)
+        ad_max = fmaxf(ad_max, ad);
+        const uint32_t bits = __builtin_bit_cast(uint32_t, ck);
         // a cell outside the grid or past the distance filter never wins; neither does a NaN or negative (sign-bit) cost
-        key[k] = (live[k] && f.c >= 0.0f) ? ((bits & ~3u) | (uint32_t)k) : 0x7f7ffffcu + (uint32_t)k;
+        key[k] = (live[k] && ck >= 0.0f) ? ((bits & ~3u) | (uint32_t)k) : 0x7f7ffffcu + (uint32_t)k;
     }
+    const float err_max = fast_cost_err(c_max, all_depth ? fast_cost_slack(ad_max, q.df800_max) : 0.0f);
     const uint32_t lo01 = key[0] < key[1] ? key[0] : key[1], hi01 = key[0] < key[1] ? key[1] : key[0];
     const uint32_t lo23 = key[2] < key[3] ? key[2] : key[3], hi23 = key[2] < key[3] ? key[3] : key[2];
     const uint32_t first = lo01 < lo23 ? lo01 : lo23;
