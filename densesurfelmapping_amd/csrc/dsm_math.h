@@ -216,7 +216,11 @@ template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, in
         q.depth_ok[j] = !q.row_in[j] | ((!q.col_ok[0] | (q.sd[j] > 0)) & (!q.col_ok[1] | (q.sd[2 + j] > 0))); // (no short cuts: lane masks)
     return q;
 }
-DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pix_d, int gw) {
+struct FastPickTrace { // what a host-side check wants to see of a pick (tests/hostemu.cpp); the kernels pass none
+    float err;
+    bool all_depth;
+};
+DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pix_d, int gw, FastPickTrace *trace = nullptr) {
     const float invd = pixel_inv_depth(pix_d);
     const bool row_ok[2] = {q.row_in[0], q.row_in[1] && y % kCell != kCell / 2};
     bool live[4];
@@ -245,6 +249,7 @@ DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pi
         key[k] = (live[k] && ck >= 0.0f) ? ((bits & ~3u) | (uint32_t)k) : 0x7f7ffffcu + (uint32_t)k;
     }
     const float err_max = fast_cost_err(c_max, all_depth ? fast_cost_slack(ad_max, q.df800_max) : 0.0f);
+    if (trace) { trace->err = err_max; trace->all_depth = all_depth; }
     const uint32_t lo01 = key[0] < key[1] ? key[0] : key[1], hi01 = key[0] < key[1] ? key[1] : key[0];
     const uint32_t lo23 = key[2] < key[3] ? key[2] : key[3], hi23 = key[2] < key[3] ? key[3] : key[2];
     const uint32_t first = lo01 < lo23 ? lo01 : lo23;
@@ -256,8 +261,8 @@ DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pi
     return kPickUnsure;
 }
 template <typename LoadSeedF>
-DSM_HD int pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeedF load) {
-    return pick_seed_fast(pick_quad(x, y, gw, gh, load), x, y, pix_i, pix_d, gw);
+DSM_HD int pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeedF load, FastPickTrace *trace = nullptr) {
+    return pick_seed_fast(pick_quad(x, y, gw, gh, load), x, y, pix_i, pix_d, gw, trace);
 }
 
 // ------------------------------------------------- robust mean depth of a seed, FF.cpp:530-556

@@ -94,6 +94,7 @@ void assign(Emu &e, bool first) {
                                         hd = e.core[s].d > 0; inv = e.inv_depth[s];
                                     });
         // the kernel's filtered pick (dsm_math.h, pick_seed_fast): wherever it answers, it must be the reference's pick
+        FastPickTrace trace = {0.0f, false};
         const int fast = pick_seed_fast(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
                                         [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &invf) {
                                             const int s = gy * e.gw + gx;
@@ -111,7 +112,20 @@ void assign(Emu &e, bool first) {
                                                 e.fast_checked++;
                                                 if (!(fabs((double)f.c - ref) <= (double)f.err)) e.fast_bound_violations++;
                                             }
-                                        });
+                                        }, &trace);
+        {
+            // the ONE bound the four candidates share must be at least every candidate's own (masked ones included)
+            const PickQuad q = pick_quad(x, y, e.gw, e.gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &invf) {
+                const int s = gy * e.gw + gx;
+                sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i; sd = e.core[s].d; invf = (float)e.inv_depth[s];
+            });
+            const float invd = pixel_inv_depth(e.D(x, y));
+            for (int k = 0; k < 4; k++) {
+                const FastCost f = pixel_cost_fast(q.sx[k], q.sy[k], q.si[k], q.sinv[k], trace.all_depth, e.I(x, y), invd, x, y);
+                e.fast_checked++;
+                if (f.err == f.err && !(f.err <= trace.err)) e.fast_bound_violations++;
+            }
+        }
         e.fast_total++;
         if (fast == kPickUnsure) { e.fast_unsure++; e.unsure_waves.insert(((long long)e.sweep_id << 40) | (long long)(y * ((e.w + 63) / 64) + x / 64)); }
         else if (fast != exact) e.fast_mismatches++;
