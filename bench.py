@@ -340,6 +340,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs beside the headline (drop-in, configs 4 and 5, node)")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed form against the CPU oracle")
+    ap.add_argument("--legs", default=os.environ.get("DSM_BENCH_LEGS", "all"),
+                    help="comma-separated legs beside the headline to run (single_sequence, dropin, fullhd, live, node, kitti_like, "
+                         "streamed, bounded_map); default all")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -356,6 +359,8 @@ def main():
     B, K, W, F = args.streams or (DEFAULT_SUBSEQUENCES if args.mode == "batched" else 8), args.steps, args.warmup, args.frames_per_step
     period = 50
     extras = rank == 0 and world == 1 and not args.no_dropin
+    legs = set(args.legs.split(","))
+    leg_on = lambda name: extras and ("all" in legs or name in legs)  # noqa: E731
 
     # ---- all synthetic frames first, on worker processes (fresh interpreters, clean environment; cached in /tmp)
     from densesurfelmapping_amd import synth
@@ -371,8 +376,14 @@ def main():
     jobs = [(cam, scenes[b], i) for b in range(n_scene) for i in range(period)]
     cam_v, scene_v = synth.VGA_RGBD, synth.Scene(seed=5, scale=0.12, step=0.05, frames_per_period=30)
     cam_h, scene_h = synth.FULLHD, synth.Scene(seed=12345, frames_per_period=10)
+    # the reference's own kind of input (kitti_publisher/scripts/publisher.py:37-40): depth = bf / quantised disparity, +inf where
+    # the disparity is 0, an image with eight grey levels and saturated highlights -- the `kitti_like` leg
+    n_scene_k = min(B, 4)
+    scenes_k = [synth.Scene(seed=12345 + 1000 * rank + 17 * b, frames_per_period=period, stereo=True, saturate_above=150.0, intensity_levels=8)
+                for b in range(n_scene_k)]
     if extras:
         jobs += [(cam_v, scene_v, i) for i in range(30)] + [(cam_h, scene_h, i) for i in range(10)]
+        jobs += [(cam, scenes_k[b], i) for b in range(n_scene_k) for i in range(period)]
     workers = max(1, min(48, (os.cpu_count() or 2) // (2 * max(world, 1))))
     t_r = time.perf_counter()
     frames_all = synth.render_many(jobs, workers)
@@ -380,6 +391,7 @@ def main():
     rendered = [frames_all[b * period:(b + 1) * period] for b in range(n_scene)]
     frames_v = frames_all[n_scene * period:n_scene * period + 30] if extras else []
     frames_h = frames_all[n_scene * period + 30:n_scene * period + 40] if extras else []
+    rendered_k = [frames_all[n_scene * period + 40 + b * period:n_scene * period + 40 + (b + 1) * period] for b in range(n_scene_k)] if extras else []
 
     import torch
     from densesurfelmapping_amd import api
@@ -637,7 +649,7 @@ def main():
             for h_ in hs:
                 h_.close()
 
-    if extras:
+    if leg_on("single_sequence"):
         # ONE sequence (BASELINE configs[1] as the reference would replay it): frames are strictly ordered, but
         # only fuse + tail need the map -- the superpixel stages of up to 8 frames run ahead on their own streams
         s1, r1, p1 = plans[0]
@@ -659,7 +671,7 @@ def main():
                                   "note": "one subsequence, one handle: the superpixel stages of depth/4 consecutive frames as one batched "
                                           "launch per kernel (three or four groups of pipelines in turn; three leave the map stream a hardware queue of its own), fuse + compaction strictly in "
                                           "frame order on the map stream; same results as the serial order"}
-    if extras:
+    if leg_on("dropin"):
         # the synchronous drop-in call (host buffers in and out over PCIe every frame), for DESIGN.md;
         # never the headline value
         ff = api.FusionFunctions.from_camera(cam, device=device, surfel_capacity=capacity)
@@ -678,7 +690,7 @@ def main():
                                                 "vector is compared with what the previous call returned (and uploaded only if the caller "
                                                 "changed it), the whole map comes back"}
         ff.close()
-    if extras:
+    if leg_on("fullhd"):
         # BASELINE configs[4]: 1920x1080 depth stream against >= 2 M live surfels, and the loop-closure deformation
         # (surfel_map.cpp:750-789).  The big map is the map of a short 1080p replay replicated
         # with millimetre jitter, so that its surfels project into the frames and take the fusion branch.
@@ -774,7 +786,7 @@ def main():
                               "timing": "HIP events around 30 back-to-back dsm_map_warp calls (704 MB moved per call)"}
         out["map_warp_8M"].update(pmc_8m("k_warp", us_w8))
         ff.close()
-    if extras:
+    if leg_on("live"):
         # BASELINE configs[3]: live callback, 640x480 RGB-D constants, one frame at a time: host frame in
         # (H2D), resident map, one hipGraph replay, wait -- the latency the 30 Hz node would see per frame
         ff = api.FusionFunctions.from_camera(cam_v, device=device, frame_slots=2, surfel_capacity=1 << 20)
@@ -793,7 +805,7 @@ def main():
                                         "map_surfels": ff.map_size(),
                                         "note": "per frame: pageable host image+depth H2D, fuse (one graph replay), stream sync; RGB-D constant set"}
         ff.close()
-    if extras:
+    if leg_on("node"):
         # the whole node through its message callbacks (stamp matching, pose graph, active /
         # inactive sets in HBM, loop closure at the start of the second lap), host-inclusive: every frame is copied into
         # the node's page-locked pool and uploaded
@@ -855,7 +867,7 @@ def main():
         for h_ in hs:
             h_.close()
 
-    if extras and args.mode == "batched":
+    if leg_on("streamed") and args.mode == "batched":
         # Frames arriving from the HOST (what a KITTI replay does: the reference receives every frame through image_input /
         # depth_input, surfel_map.cpp:83-101) instead of a scene period resident in HBM: the same batched replay with 2 x C
         # frame slots per subsequence, chunk k + 1 sent up from page-locked memory (dsm_frame_upload_async, one transfer
@@ -934,7 +946,76 @@ def main():
         for pf in pins:
             pf.close()
 
-    if extras and args.mode == "batched":
+    if leg_on("kitti_like") and args.mode == "batched":
+        # The reference's REAL input distribution through the timed form: the same batched replay on frames
+        # as kitti_publisher makes them -- depth = 386.1448 / disparity with the disparity in steps of 1/16 and +inf where
+        # it is 0, eight grey levels, saturated highlights.  A tenth of the first sweep's pixels then lie exactly between
+        # two seeds that the fp32 cost filter cannot tell apart (k_assign's list of open picks), most seeds of the sky end
+        # with an infinite mean depth, and the maps fill with non-finite surfels as the reference's do.
+        def make_handle_k(b):
+            ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=period, surfel_capacity=capacity, pipeline_depth=1)
+            for i, (img, dep) in enumerate(rendered_k[b % n_scene_k]):
+                ff.frame_upload(i, img, dep)
+            ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+            return ff
+
+        def plan_k(b, n):
+            ph = (b // n_scene_k) * 7 % period
+            return api.FusionFunctions.pack_replay([(t + ph) % period for t in range(n)], [t // 5 for t in range(n)],
+                                                   np.stack([scenes_k[b % n_scene_k].pose(t + ph) for t in range(n)]))
+        k_k, w_k = min(K, 10), 3
+        n_k = (w_k + k_k) * F
+        hs = [make_handle_k(b) for b in range(B)]
+        pl_k = [plan_k(b, n_k) for b in range(B)]
+        bts = [api.Batch([hs[b] for b in grp]) for grp in groups_b]
+
+        def run_k(lo, hi):
+            def one(g):
+                for c0 in range(lo, hi, 64):
+                    c1 = min(hi, c0 + 64)
+                    sb, rb, pb, nn = api.Batch.pack([(pl_k[b][0][c0:c1], pl_k[b][1][c0:c1], pl_k[b][2][c0:c1]) for b in groups_b[g]])
+                    bts[g].replay_enqueue(sb, rb, pb, nn)
+            list(pool.map(one, range(n_bat)))
+            for bt_ in bts:
+                bt_.synchronize()
+        run_k(0, w_k * F)
+        t_k = time.perf_counter()
+        run_k(w_k * F, n_k)
+        dt_k = time.perf_counter() - t_k
+        fps_k = B * k_k * F / dt_k
+        sizes_k = [h_.map_size() for h_ in hs]
+        nonfinite = int(sum((~np.isfinite(m_[f])).sum() for m_ in [hs[0].map_download()] for f in m_.dtype.names if m_[f].dtype.kind == "f"))
+        for bt_ in bts:
+            bt_.close()
+        # the sweep kernels of ONE batch alone on the GPU, by HIP events (as `roofline` does for the default scenes)
+        nb = len(groups_b[0])
+        bt = api.Batch(hs[:nb])  # (any nb handles: all are in step)
+        sb, rb, pb, nn = api.Batch.pack([(pl_k[b][0][:24], pl_k[b][1][:24], pl_k[b][2][:24]) for b in range(nb)])
+        stk, _ = bt.replay_timed(sb, rb, pb, nn)
+        ovk = bt.event_overhead_ms * 1e3
+        perk = {k: max(v[0] / max(v[1], 1) * 1e3 - ovk, 0.0) for k, v in stk.items()}
+        bt.close()
+        for h_ in hs:
+            h_.close()
+        open_picks = None
+        try:
+            open_picks = json.load(open(os.path.join(ROOT, "profiles", "r05_open_picks.json")))
+        except (OSError, ValueError):
+            pass
+        out["kitti_like"] = {"value": round(fps_k, 1), "unit": "frames/s", "fraction_of_headline": round(fps_k / (fps / world), 3),
+                             "subsequences": B, "steps": k_k, "mean_live_surfels": round(float(np.mean(sizes_k))),
+                             "nonfinite_fields_in_map_0": nonfinite,
+                             "batched_kernel_us": {k: round(v, 2) for k, v in perk.items()},
+                             "assign_us_per_launch": [round(perk.get(k, 0.0), 2) for k in ("assign_0", "assign_1", "assign_2")],
+                             "assign_us_per_launch_default_scenes": ([out["batched_kernel_us"].get(k) for k in ("assign_0", "assign_1", "assign_2")]
+                                                                     if "batched_kernel_us" in out else None),
+                             "open_picks": open_picks,
+                             "input": "depth = float32(386.1448) / disparity, disparity = round(16 bf / z) / 16, 0 (-> +inf) on holes and sky "
+                                      "(kitti_publisher/scripts/publisher.py:37-40); image quantised to 8 grey levels, 255 above 150",
+                             "note": f"the headline's form ({n_bat} batches of {nb} in flight) on {n_scene_k} stereo scenes; parity of this input "
+                                     "family: tests/test_gpu_scale.py [stereo_inf, stereo_zero] against reference-TU vectors"}
+
+    if leg_on("bounded_map") and args.mode == "batched":
         # The headline replay never lets a keyframe leave the window, so its maps grow without bound and 83 % of B_alg is
         # the 88 B/surfel map term.  The node keeps the surfels of the ~10 drift-free keyframes active (SM.cpp:154,
         # 1456-1595: move_add_surfels): the same batched replay with every handle's keyframes older than 10 moved to its

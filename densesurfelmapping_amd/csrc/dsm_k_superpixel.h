@@ -208,6 +208,9 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
     __shared__ float s_invf[kTileCellsX * kTileCellsY]; // the same rounded to float, for the filtered pick
+    // the tile's pixels whose pick the fp32 filter leaves open (tile row << 6 | tile column), for the dense pass below
+    __shared__ unsigned short s_open[kTileW * kTileH];
+    __shared__ int s_n_open;
     const FrameParams &fp = frame_params(c);
     const uint8_t *img = frame_image(c, fp);
     const float *dep = frame_depth(c, fp);
@@ -216,6 +219,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     const int bx = blk.x * kTileW, by = blk.y * kTileH;
     const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
     const int tid = threadIdx.x;
+    if (tid == 0) s_n_open = 0;
     if (tid < kTileCellsX * kTileCellsY) {
         const int gx = cx0 + tid % kTileCellsX, gy = cy0 + tid / kTileCellsX;
         if (gx >= 0 && gx < gw && gy >= 0 && gy < gh) {
@@ -226,49 +230,8 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         }
     }
     __syncthreads();
-    const int x = bx + (tid & (kTileW - 1)), y0 = by + (tid / kTileW) * kColumn; // y0 is a multiple of 4: one quadrant row
-    if (x >= w || y0 >= h) return;
-    // the column's pixels, one round trip
-    float pix_i[kColumn], pix_d[kColumn];
-    int lab[kColumn];
-    const unsigned p0 = (unsigned)(__mul24(y0, pitch) + x);
-#pragma unroll
-    for (int r = 0; r < kColumn; r++) {
-        const unsigned p = y0 + r < h ? p0 + (unsigned)(r * pitch) : p0, p4 = p << 2; // byte offsets into the 4-byte planes, see ld_off
-        pix_i[r] = (float)ld_off(img, p);
-        pix_d[r] = ld_off(dep, p4);
-        lab[r] = FIRST ? 0 : label_at(label_in, p);
-    }
-    const PickQuad quad = pick_quad(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &inv_f) {
-        const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
-        const float4 v = s_core[li];
-        sx = v.x; sy = v.y; si = v.z; sd = v.w;
-        inv_f = s_invf[li];
-    });
-#pragma unroll
-    for (int r = 0; r < kColumn; r++) {
-        const int y = y0 + r;
-        if (y >= h) break;
-        const int p = (int)p0 + r * pitch;
-        if (!has_candidate_cell(x, y, gw, gh)) {
-            // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
-            // every seed window ends before them, and k_apply_labels keeps a -1)
-            if (FIRST) label_put(c->label, (unsigned)p, -1);
-            continue;
-        }
-        // the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast); the few
-        // near-ties of a wave take the reference's typed arithmetic
-        int pick = pick_seed_fast(quad, x, y, pix_i[r], pix_d[r], gw);
-        if (pick == kPickUnsure)
-            pick = pick_seed(x, y, pix_i[r], pix_d[r], gw, gh,
-                             [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
-                                 const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
-                                 const float4 v = s_core[li];
-                                 sx = v.x; sy = v.y; si = v.z;
-                                 has_d = v.w > 0;
-                                 inv_d = s_inv[li];
-                             });
-        const int l = lab[r];
+    // what becomes of a pixel once its pick is known (FF.cpp:442-451 and the stable-skip bookkeeping, see resolve_worklist)
+    auto settle = [&](int p, int l, int pick) {
         if (pick < 0) { // every candidate cost >= the reference's 1e6 sentinel: it would index seeds[-1]
             atomicOr(c->status, kStatusBadPick);
             if (FIRST) label_put(c->label, (unsigned)p, 0); else label_put(c->cand, (unsigned)p, l);
@@ -288,6 +251,73 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
                 c->worklist[slot] = p;
             }
         }
+    };
+    const int x = bx + (tid & (kTileW - 1)), y0 = by + (tid / kTileW) * kColumn; // y0 is a multiple of 4: one quadrant row
+    if (x < w && y0 < h) { // (no early return: every thread meets the barrier below)
+        // the column's pixels, one round trip
+        float pix_i[kColumn], pix_d[kColumn];
+        int lab[kColumn];
+        const unsigned p0 = (unsigned)(__mul24(y0, pitch) + x);
+#pragma unroll
+        for (int r = 0; r < kColumn; r++) {
+            const unsigned p = y0 + r < h ? p0 + (unsigned)(r * pitch) : p0, p4 = p << 2; // byte offsets into the 4-byte planes, see ld_off
+            pix_i[r] = (float)ld_off(img, p);
+            pix_d[r] = ld_off(dep, p4);
+            lab[r] = FIRST ? 0 : label_at(label_in, p);
+        }
+        const PickQuad quad = pick_quad(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &inv_f) {
+            const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
+            const float4 v = s_core[li];
+            sx = v.x; sy = v.y; si = v.z; sd = v.w;
+            inv_f = s_invf[li];
+        });
+#pragma unroll
+        for (int r = 0; r < kColumn; r++) {
+            const int y = y0 + r;
+            if (y >= h) break;
+            const int p = (int)p0 + r * pitch;
+            if (!has_candidate_cell(x, y, gw, gh)) {
+                // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
+                // every seed window ends before them, and k_apply_labels keeps a -1)
+                if (FIRST) label_put(c->label, (unsigned)p, -1);
+                continue;
+            }
+            // the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast).  A pixel it
+            // leaves open goes onto the tile's list: the reference's typed arithmetic is several hundred instructions, and
+            // run here it would run for the whole wave whenever ONE of its 64 pixels is open -- 16 % of the wave-rows on
+            // smooth synthetic depth, and most of them on the reference's own kind of input (kitti_publisher: depth = bf /
+            // quantised disparity, a few grey levels), where a tenth of the first sweep's pixels sit exactly between two
+            // seeds of equal intensity whose inverse depths lie on the disparity lattice.
+            const int pick = pick_seed_fast(quad, x, y, pix_i[r], pix_d[r], gw);
+            const bool open = pick == kPickUnsure;
+            const unsigned long long m = __ballot(open);
+            if (m) {
+                const int rk = rank_below(m);
+                int base = 0;
+                if (open && rk == 0) base = atomicAdd(&s_n_open, __popcll(m));
+                base = __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1);
+                if (open) s_open[base + rk] = (unsigned short)((((tid / kTileW) * kColumn + r) << 6) | (tid & (kTileW - 1)));
+            }
+            if (!open) settle(p, lab[r], pick);
+        }
+    }
+    __syncthreads();
+    // ---- the open pixels of the tile, packed: 64 to a wave whatever rows and columns they came from
+    const int n_open = s_n_open;
+    for (int i = tid; i < n_open; i += 256) {
+        const unsigned e = s_open[i];
+        const int ox = bx + (int)(e & 63u), oy = by + (int)(e >> 6);
+        const unsigned p = (unsigned)(__mul24(oy, pitch) + ox);
+        const float pi = (float)ld_off(img, p), pd = ld_off(dep, p << 2);
+        const int l = FIRST ? 0 : label_at(label_in, p);
+        const int pick = pick_seed(ox, oy, pi, pd, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, bool &has_d, double &inv_d) {
+            const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
+            const float4 v = s_core[li];
+            sx = v.x; sy = v.y; si = v.z;
+            has_d = v.w > 0;
+            inv_d = s_inv[li];
+        });
+        settle((int)p, l, pick);
     }
 }
 

@@ -77,6 +77,15 @@ class Scene:
     max_depth: float = 80.0
     n_boxes: int = 10
     scale: float = 1.0               # shrink the whole scene (RGB-D range tests)
+    # ---- the reference's real feed (kitti_publisher/scripts/publisher.py:37-40): depth = bf / disparity of a stereo
+    # matcher -- disparity-quantised, and `x / 0` = +inf wherever the matcher left disparity 0 (sky, occlusions) --
+    # and a camera image with saturated highlights and few grey levels
+    stereo: bool = False
+    stereo_bf: float = 386.1448      # baseline x focal of sequences 00-02, publisher.py:38
+    disparity_step: float = 0.0625   # sub-pixel resolution of the disparity map
+    zero_disparity_inf: bool = True  # False: an unmatched pixel is depth 0 (a publisher that masks them)
+    saturate_above: float = 0.0      # > 0: every grey value above it reads 255
+    intensity_levels: int = 0        # > 0: the grey values below saturation quantised to this many levels
 
     @property
     def period(self) -> float:
@@ -173,17 +182,34 @@ def render(cam: Camera, scene: Scene, t: int):
     salt = scene.seed * 2654435761 + tl * 40503
     n_int = _uniform01(pix, salt + 1) * scene.intensity_noise
     img = np.where(hit, albedo + chk + n_int, 200.0 + n_int)  # sky is bright
-    image = np.clip(np.floor(img), 0, 255).astype(np.uint8)
+    img = np.clip(np.floor(img), 0, 255)
+    if scene.intensity_levels > 0:
+        q = 256.0 / scene.intensity_levels
+        img = np.floor(img / q) * q
+    if scene.saturate_above > 0:
+        img = np.where(img > scene.saturate_above, 255.0, img)
+    image = img.astype(np.uint8)
     n_d = _uniform01(pix, salt + 2) - 0.5
     depth = tt * (1.0 + scene.depth_noise * n_d)  # camera-frame z == ray parameter (dir_c.z = 1)
     holes = _uniform01(pix, salt + 3) < scene.hole_fraction
+    if scene.stereo:
+        # what a stereo matcher hands to publisher.py: a float32 disparity map in steps of `disparity_step`, 0 where it
+        # found no match; depth = float32(bf) / disparity, so +inf there (numpy's x / 0), exactly representable
+        # disparities elsewhere: neighbouring pixels of a far surface share their depth bit for bit
+        with np.errstate(divide="ignore", invalid="ignore"):
+            disp = np.where(hit & ~holes, (scene.stereo_bf * sc) / depth, 0.0)
+            disp = (np.round(disp / scene.disparity_step) * scene.disparity_step).astype(np.float32)
+            depth = (np.float32(scene.stereo_bf * sc) / disp).astype(np.float32)
+        if not scene.zero_disparity_inf:
+            depth = np.where(np.isfinite(depth), depth, np.float32(0.0)).astype(np.float32)
+        return image, depth, pose
     depth = np.where(hit & ~holes, depth, 0.0).astype(np.float32)
     return image, depth, pose
 
 
 def _job_key(cam: Camera, scene: Scene, t: int) -> str:
     import hashlib
-    return hashlib.sha256(repr((dataclasses.astuple(cam), dataclasses.astuple(scene), int(t), "v1")).encode()).hexdigest()[:32]
+    return hashlib.sha256(repr((dataclasses.astuple(cam), dataclasses.astuple(scene), int(t), "v2")).encode()).hexdigest()[:32]
 
 
 def render_many(jobs, workers: int = 0, cache_dir: str = "/tmp/dsm_synth_cache"):

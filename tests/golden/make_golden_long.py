@@ -31,8 +31,18 @@ def map_sha(a):
     return hashlib.sha256(_canon(np.ascontiguousarray(a, SURFEL_DTYPE))).hexdigest()
 
 
-def long_sequence():
-    case = {"name": "kitti1226_drive_200", "camera": "KITTI_1226", "scene": {"seed": 12345}, "frames": 200, "checkpoint_every": 50}
+LONG = {"name": "kitti1226_drive_200", "camera": "KITTI_1226", "scene": {"seed": 12345}, "frames": 200, "checkpoint_every": 50}
+# The reference's real feed (kitti_publisher/scripts/publisher.py:37-40): depth = bf / disparity -- disparity-quantised,
+# +inf where the disparity is 0 -- and an image with saturated highlights and eight grey levels; once with the
+# infinities as the publisher sends them, once with those pixels at depth 0 (a publisher that masks them).
+_STEREO = {"seed": 12345, "stereo": True, "saturate_above": 150.0, "intensity_levels": 8}
+STEREO = [
+    {"name": "kitti1226_stereo_inf_60", "camera": "KITTI_1226", "scene": dict(_STEREO), "frames": 60, "checkpoint_every": 20},
+    {"name": "kitti1226_stereo_zero_60", "camera": "KITTI_1226", "scene": dict(_STEREO, zero_disparity_inf=False), "frames": 60, "checkpoint_every": 20},
+]
+
+
+def long_sequence(case=LONG):
     cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
     ref = RefOracle(cam)
     local = np.zeros(0, SURFEL_DTYPE)
@@ -46,7 +56,8 @@ def long_sequence():
             checkpoints[str(t + 1)] = map_sha(local)
             print(case["name"], "frame", t + 1, "surfels", len(local), flush=True)
     return dict(case, per_frame=per_frame, map_sha256=checkpoints,
-                n_mature=int((local["update_times"] >= 5).sum()))
+                n_mature=int((local["update_times"] >= 5).sum()),
+                n_nonfinite=int(sum((~np.isfinite(local[f])).sum() for f in SURFEL_DTYPE.names if local[f].dtype.kind == "f")))
 
 
 def large_map(case):
@@ -69,10 +80,15 @@ def large_map(case):
 
 
 def main():
-    out = {"generator": "oracle/_ref/libdsm_ref_serial.so (reference fusion_functions.cpp, serial thread schedule)",
-           "sequence": long_sequence(), "large_map": large_map(scale_cases.LARGE_MAP),
-           "fullhd_2m": large_map(scale_cases.FULLHD_2M)}
-    with open(os.path.join(HERE, "long_golden.json"), "w") as f:
+    path = os.path.join(HERE, "long_golden.json")
+    if "--only-stereo" in sys.argv:  # add / refresh the stereo sequences, keep the rest of the record
+        out = json.load(open(path))
+    else:
+        out = {"generator": "oracle/_ref/libdsm_ref_serial.so (reference fusion_functions.cpp, serial thread schedule)",
+               "sequence": long_sequence(), "large_map": large_map(scale_cases.LARGE_MAP),
+               "fullhd_2m": large_map(scale_cases.FULLHD_2M)}
+    out["stereo_sequences"] = [long_sequence(c) for c in STEREO]
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
 
 

@@ -45,6 +45,7 @@ struct Emu {
     long long exact_stats[5] = {0, 0, 0, 0, 0};
     long long exact_operand_pass = 0; // steps 2..5 that pass the cheaper OPERAND-level test: range(r) + range(p_a) + 1 <= 21 for every a
     long long fast_total = 0, fast_unsure = 0, fast_mismatches = 0, fast_checked = 0, fast_bound_violations = 0; // pick_seed_fast
+    long long unsure_by_sweep[kSweeps] = {0, 0, 0};
 
     float I(int x, int y) const { return (float)img[(size_t)y * img_step + x]; }
     float D(int x, int y) const { return *(const float *)((const char *)dep + (size_t)y * dep_step + (size_t)x * 4); }
@@ -127,7 +128,7 @@ void assign(Emu &e, bool first) {
             }
         }
         e.fast_total++;
-        if (fast == kPickUnsure) { e.fast_unsure++; e.unsure_waves.insert(((long long)e.sweep_id << 40) | (long long)(y * ((e.w + 63) / 64) + x / 64)); }
+        if (fast == kPickUnsure) { e.fast_unsure++; e.unsure_by_sweep[(e.sweep_id - 1) % kSweeps]++; e.unsure_waves.insert(((long long)e.sweep_id << 40) | (long long)(y * ((e.w + 63) / 64) + x / 64)); }
         else if (fast != exact) e.fast_mismatches++;
         const int pick = fast == kPickUnsure ? exact : fast;
         if (first) { e.label[p] = pick; continue; }
@@ -415,7 +416,7 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
 void emu_exact_sum_stats(void *p, long long *out) { for (int i = 0; i < 5; i++) out[i] = ((Emu *)p)->exact_stats[i]; out[5] = ((Emu *)p)->exact_operand_pass; }
-// pick_seed_fast over every pixel assigned so far: out[12] (7: seeds with a non-core residual at step 1; 8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
+// pick_seed_fast over every pixel assigned so far: out[24] (12..14: undecided picks by sweep; 7: seeds with a non-core residual at step 1; 8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
 // out[0..7] = [pixels, unsure, answered differently from pick_seed, costs checked,
 // bound violated, 64-pixel row segments (waves) with an unsure pixel, sweeps]
 void emu_fast_pick_stats(void *p, long long *out) {
@@ -424,6 +425,7 @@ void emu_fast_pick_stats(void *p, long long *out) {
     out[7] = e.gn_first_noncore;
     out[8] = e.gn_seeds; out[9] = e.gn_seeds_mask_changed; out[10] = e.gn_steps; out[11] = e.gn_steps_mask_changed;
     out[0] = e.fast_total; out[1] = e.fast_unsure; out[2] = e.fast_mismatches; out[3] = e.fast_checked; out[4] = e.fast_bound_violations;
+    for (int i = 0; i < kSweeps; i++) out[12 + i] = e.unsure_by_sweep[i]; // (out[24])
 }
 
 int emu_fuse_map(void *p, int ref_idx, const uint8_t *img, size_t img_step, const float *depth, size_t depth_step,

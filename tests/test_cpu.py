@@ -138,14 +138,23 @@ class Emu:
         return out
 
 
-@pytest.mark.parametrize("camera,frames,salt", [("TINY", 48, 0), ("TINY", 48, 977), ("KITTI_1226", 3, 12345),
-                                                 ("VGA_RGBD", 2, 0), ("TINY_RAGGED", 30, 0), ("TINY_RAGGED", 30, 555)])
-def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
+# the reference's real feed (publisher.py:37-40): disparity-quantised depth, +inf at zero disparity, saturated / 8-level image
+STEREO_SCENE = dict(stereo=True, saturate_above=150.0, intensity_levels=8)
+
+
+@pytest.mark.parametrize("camera,frames,salt,stereo", [("TINY", 48, 0, None), ("TINY", 48, 977, None), ("KITTI_1226", 3, 12345, None),
+                                                        ("VGA_RGBD", 2, 0, None), ("TINY_RAGGED", 30, 0, None), ("TINY_RAGGED", 30, 555, None),
+                                                        ("TINY", 30, 0, "inf"), ("TINY", 30, 311, "zero"), ("KITTI_1226", 3, 0, "inf")])
+def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt, stereo):
     """dsm_math.h + the tmin/worklist fixed point, staged seed commit, 20-lane Gauss-Newton and the
     parallel-exact compaction, executed serially (and in scrambled order when salt != 0), bit-equal to
-    the oracle."""
+    the oracle.  `stereo`: the same on the reference's kind of input -- depth = bf / quantised disparity with +inf (or 0)
+    where the disparity is 0, few grey levels -- where seeds end with an infinite or NaN mean depth and the filtered
+    pick meets ten times as many near-ties."""
     cam = getattr(synth, camera)
     scene = synth.Scene(seed=5, scale=0.12, step=0.05) if cam.rgbd else synth.Scene()
+    if stereo:
+        scene = synth.Scene(zero_disparity_inf=stereo == "inf", **STEREO_SCENE)
     emu, orc = Emu(hostemu_lib, cam), ob.PortOracle(cam)
     emu.lib.emu_set_order_salt(emu.h, salt)
     le = np.zeros(0, ob.SURFEL_DTYPE)
@@ -159,13 +168,13 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
         assert not fields_equal(le, lo), t
     # the filtered pick of k_assign (dsm_math.h, pick_seed_fast), run beside the reference's on every pixel of every sweep:
     # it never answers differently, its error bound holds on every candidate cost, and it answers nearly always
-    st = (C.c_longlong * 12)()
+    st = (C.c_longlong * 24)()
     emu.lib.emu_fast_pick_stats.argtypes = [C.c_void_p, C.c_void_p]
     emu.lib.emu_fast_pick_stats(emu.h, st)
     pixels, unsure, mismatches, checked, violations = list(st)[:5]
     assert pixels >= frames * 3 * cam.width * cam.height * 0.9 and checked > pixels
     assert mismatches == 0 and violations == 0, (mismatches, violations)
-    assert unsure < 0.02 * pixels, (unsure, pixels)
+    assert unsure < (0.06 if stereo else 0.02) * pixels, (unsure, pixels)
     # the exact-sum claim behind k_seed_fit's tree-ordered Jacobian sums (tools/_exp/r04_fit_tree.patch, row16_sum): fp32-product terms
     # spanning <= 21 binades sum exactly in double in ANY order -- on every qualifying sum of every fitted seed a 16-way
     # tree gives the ordered sum's bits, and nearly every all-core step qualifies
@@ -173,7 +182,7 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt):
     emu.lib.emu_exact_sum_stats.argtypes = [C.c_void_p, C.c_void_p]
     emu.lib.emu_exact_sum_stats(emu.h, ex)
     assert ex[3] == 0, f"{ex[3]} qualifying sums whose tree-order value differs from the ordered one"
-    assert ex[2] == 0 or ex[1] >= 0.95 * ex[2], (ex[1], ex[2])
+    assert stereo or ex[2] == 0 or ex[1] >= 0.95 * ex[2], (ex[1], ex[2])  # (a statistic of the smooth scenes; NaN / inf planes never qualify)
     print(f"exact sums: steps 2..5 whose Jacobian sums all span <= 21 binades: {ex[1]} of {ex[2]}; step-1 (H and J): {ex[0]} of {st[8]} seeds; tree == ordered on all")
     print(f"plane fit: {st[7]} of {st[8]} seeds with a residual outside the Huber core at step 1, {st[9]} with a class change later")
     print(f"pick_seed_fast: {unsure} of {pixels} pixels unsure ({100.0 * unsure / pixels:.3f} %), {checked} costs within their bound")
@@ -853,16 +862,17 @@ def test_port_oracle_matches_long_golden(ob, synth):
     byte when a digest differs, so it is pinned at these sizes too."""
     import scale_cases
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "long_golden.json")))
-    case = gold["sequence"]
-    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
-    orc = ob.PortOracle(cam)
-    local = np.zeros(0, ob.SURFEL_DTYPE)
-    for (t, img, dep, pose, ref), want in zip(synth.sequence(cam, scene, case["frames"]), case["per_frame"]):
-        local, k = orc.fuse_map(ref, img, dep, pose, local)
-        assert (k, len(local)) == (want["n_new"], want["n_local"]), t
-        assert hashlib.sha256(orc.labels().tobytes()).hexdigest() == want["labels_sha256"], t
-        if str(t + 1) in case["map_sha256"]:
-            assert _map_sha(local, ob.SURFEL_DTYPE) == case["map_sha256"][str(t + 1)], t
+    assert gold["stereo_sequences"][0]["n_nonfinite"] > 0, "the +inf feed leaves no non-finite surfel: the case lost its point"
+    for case in [gold["sequence"]] + gold["stereo_sequences"]:  # (stereo: the reference's real feed, publisher.py:37-40)
+        cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+        orc = ob.PortOracle(cam)
+        local = np.zeros(0, ob.SURFEL_DTYPE)
+        for (t, img, dep, pose, ref), want in zip(synth.sequence(cam, scene, case["frames"]), case["per_frame"]):
+            local, k = orc.fuse_map(ref, img, dep, pose, local)
+            assert (k, len(local)) == (want["n_new"], want["n_local"]), (case["name"], t)
+            assert hashlib.sha256(orc.labels().tobytes()).hexdigest() == want["labels_sha256"], (case["name"], t)
+            if str(t + 1) in case["map_sha256"]:
+                assert _map_sha(local, ob.SURFEL_DTYPE) == case["map_sha256"][str(t + 1)], (case["name"], t)
     for key, sc in (("large_map", scale_cases.LARGE_MAP), ("fullhd_2m", scale_cases.FULLHD_2M)):
         cam = getattr(synth, sc["camera"])
         big, (t, img, dep, pose, ref) = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, sc)

@@ -479,6 +479,19 @@ def test_edge_inputs(mods):
     half = cases["flat wall"][1].copy()
     half[::2] = 0.0
     cases["striped holes"] = (cases["noise"][0], half)
+    # what a publisher can hand over besides metres (kitti_publisher/scripts/publisher.py:38 divides by the disparity: +inf
+    # where it is 0): non-finite and negative depths, alone and mixed into ordinary ones
+    nd = cases["noise"][1]
+    u = rng.random(nd.shape)
+    cases["inf sky"] = (cases["noise"][0], np.where(np.arange(cam.height)[:, None] < cam.height // 3, np.float32(np.inf), cases["flat wall"][1]).astype(np.float32))
+    cases["all inf"] = (cases["flat wall"][0], np.full(nd.shape, np.inf, np.float32))
+    cases["inf speckle"] = (cases["noise"][0], np.where(u < 0.1, np.float32(np.inf), nd).astype(np.float32))
+    cases["nan speckle"] = (cases["noise"][0], np.where(u < 0.1, np.float32(np.nan), nd).astype(np.float32))
+    cases["negative speckle"] = (cases["noise"][0], np.where(u < 0.1, -nd - 1.0, nd).astype(np.float32))
+    cases["everything"] = (cases["noise"][0], np.where(u < 0.05, np.float32(np.inf), np.where(u < 0.1, np.float32(np.nan),
+                                                       np.where(u < 0.15, np.float32(-np.inf), np.where(u < 0.2, -nd, nd)))).astype(np.float32))
+    # few grey levels over a flat wall: whole regions of exact cost ties (the first candidate in scan order wins, FF.cpp:430)
+    cases["two greys"] = (np.where((np.arange(cam.width)[None, :] // 24 + np.arange(cam.height)[:, None] // 16) % 2, 64, 192).astype(np.uint8), cases["flat wall"][1])
     for name, (img, dep) in cases.items():
         lg, kg = ff.fuse_map(0, img, dep, pose, np.zeros(0, api.SURFEL_DTYPE))
         lo, ko = orc.fuse_map(0, img, dep, pose, np.zeros(0, ob.SURFEL_DTYPE))

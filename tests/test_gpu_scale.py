@@ -40,12 +40,27 @@ def map_sha(a, dtype):
     return hashlib.sha256(_canon(np.ascontiguousarray(a, dtype))).hexdigest()
 
 
-def test_long_sequence_kitti_golden(mods, gold):
+# The sequences of long_golden.json (reference-TU vectors): the 200-frame smooth-noise drive, and the reference's REAL kind
+# of input as kitti_publisher/scripts/publisher.py:37-40 makes it -- depth = bf / disparity, disparity-quantised, +inf
+# where the disparity is 0 (`stereo_inf`; `stereo_zero`: those pixels at depth 0), an image with eight grey levels and
+# saturated highlights: seeds with infinite and NaN mean depths, non-finite surfels, and a tenth of the first sweep's
+# pixels exactly between two seeds (k_assign's list of open picks is the common case there, not the exception).
+SEQUENCES = ["drive200", "stereo_inf", "stereo_zero"]
+
+
+@pytest.fixture(params=SEQUENCES)
+def seq_case(request, gold):
+    if request.param == "drive200":
+        return gold["sequence"]
+    return gold["stereo_sequences"][SEQUENCES.index(request.param) - 1]
+
+
+def test_long_sequence_kitti_golden(mods, seq_case):
     """200 frames at 1226x370: per frame the label image (SHA-256), new and total surfel counts; every 50 frames the
     whole map; first frame by frame (one graph replay each), then again as four 50-frame batches with the default
     frame pipelining.  Vectors: the reference TU."""
     api, synth, ob = mods
-    case = gold["sequence"]
+    case = seq_case
     cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
     period = scene.frames_per_period
     frames = list(synth.sequence(cam, scene, case["frames"]))
@@ -54,7 +69,10 @@ def test_long_sequence_kitti_golden(mods, gold):
     assert sum(f["n_holes"] for f in per) > 1000, "no pruning / deletion in the golden run"
     assert any(f["n_holes"] > f["n_new"] for f in per), "the K < k branch (swap-with-last) never fires"
     assert any(0 < f["n_holes"] < f["n_new"] for f in per), "the K > k branch (refill + append) never fires"
-    assert case["n_mature"] > 1000
+    if case["name"] == "kitti1226_drive_200":
+        assert case["n_mature"] > 1000
+    if case["name"] == "kitti1226_stereo_inf_60":
+        assert case["n_nonfinite"] > 10000, "the +inf feed leaves no non-finite surfels: the case lost its point"
 
     ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20)
     for t in range(period):
@@ -88,13 +106,13 @@ def test_long_sequence_kitti_golden(mods, gold):
         ff.close()
 
 
-def test_long_sequence_kitti_golden_batched(mods, gold):
+def test_long_sequence_kitti_golden_batched(mods, seq_case):
     """The headline configuration of bench.py against the same vectors: EIGHT handles advancing in lockstep through the
     200 frames at 1226x370, every kernel launched once for all of them (one handle per XCD, the plane fit in its two
     tiers).  Handle b is 7 - b frames ahead of handle 7, so no two ever work on the same frame; every handle's map
     after its own 50th / 100th / 150th / 200th frame is the reference TU's, and so are its labels after its 200th."""
     api, synth, ob = mods
-    case = gold["sequence"]
+    case = seq_case
     cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
     period = scene.frames_per_period
     n, B = case["frames"], 8
@@ -142,7 +160,7 @@ def test_long_sequence_kitti_golden_batched(mods, gold):
         ff.close()
 
 
-def test_four_batches_in_flight_against_the_golden(mods, gold):
+def test_four_batches_in_flight_against_the_golden(mods, seq_case):
     """The exact form bench.py times: FOUR batches of 32 handles, each batch enqueued by its own host thread on its own
     stream, all in flight at once (128 subsequences sharing the machine, four of them per XCD in every launch, graphs
     captured concurrently at the first frame) -- here every one of the 128 replays the 200-frame 1226x370 golden
@@ -150,7 +168,7 @@ def test_four_batches_in_flight_against_the_golden(mods, gold):
     reference TU's."""
     import threading
     api, synth, ob = mods
-    case = gold["sequence"]
+    case = seq_case
     cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
     period, n, step = scene.frames_per_period, case["frames"], case["checkpoint_every"]
     frames = list(synth.sequence(cam, scene, n))
@@ -194,7 +212,7 @@ def test_four_batches_in_flight_against_the_golden(mods, gold):
         ff.close()
 
 
-def test_long_sequence_streamed_input(mods, gold):
+def test_long_sequence_streamed_input(mods, seq_case):
     """Frames arriving from the host instead of sitting in HBM (the reference receives every frame through image_input /
     depth_input, surfel_map.cpp:83-101): the 200-frame 1226x370 golden sequence again, every handle with only 2 x 10
     frame slots, chunks of ten frames sent up with dsm_frame_upload_async from page-locked memory while the previous
@@ -202,7 +220,7 @@ def test_long_sequence_streamed_input(mods, gold):
     and the bench's form, EIGHT handles in one batch (handle b starts the sequence b frames late ... all pass the same
     checkpoints).  Maps and labels are the reference TU's: streamed == resident, byte for byte."""
     api, synth, ob = mods
-    case = gold["sequence"]
+    case = seq_case
     cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
     n, step, C = case["frames"], case["checkpoint_every"], 10
     frames = list(synth.sequence(cam, scene, n))
