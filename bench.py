@@ -221,6 +221,35 @@ def canon_bytes(a: np.ndarray) -> bytes:
     return words.tobytes()
 
 
+def oracle_replay_worker(spec_json):
+    """`python bench.py --oracle-replay-worker '<json>'`: the CPU oracle's replay of one subsequence of the headline from an
+    empty map through frame `frames` - 1 -- the CHECKER of the timed region (started beside the GPU run, never inside a timed
+    interval); prints the NaN-canonical SHA-256 of the whole map."""
+    import hashlib
+    from densesurfelmapping_amd import synth
+    from oracle.bindings import SURFEL_DTYPE as O_DTYPE, PortOracle
+    spec = json.loads(spec_json)
+    cam = getattr(synth, spec["camera"])
+    scene = synth.Scene(seed=spec["seed"], frames_per_period=spec["period"])
+    per = spec["period"]
+    frames = synth.render_many([(cam, scene, i) for i in range(per)], workers=1)  # (rendered and cached by the parent already)
+    orc, lo = PortOracle(cam), np.zeros(0, O_DTYPE)
+    for t in range(spec["frames"]):
+        img, dep = frames[(t + spec["phase"]) % per]
+        lo, _ = orc.fuse_map(t // 5, img, dep, scene.pose(t + spec["phase"]), lo)
+    print(json.dumps({"subsequence": spec["subsequence"], "frames": spec["frames"], "surfels": int(len(lo)),
+                      "sha256": hashlib.sha256(canon_bytes(lo)).hexdigest()}), flush=True)
+
+
+def start_oracle_replays(specs):
+    """one fresh interpreter per spec (clean environment: nothing inherited from rocprofv3 / torchrun), all at once"""
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER", "LD_PRELOAD", "OMP_", "MKL_")) or k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))}
+    env["OMP_NUM_THREADS"] = "1"
+    return [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-replay-worker", json.dumps(sp)], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, env=env, cwd=ROOT, text=True) for sp in specs]
+
+
 def cpu_baseline(cam, scene, rendered, period, lo, hi, budget_s=25.0):
     """The reference's own fusion_functions.cpp (oracle/_ref, real 10-thread schedule) if its prebuilt library is
     present, else our C restatement (1 thread).  Replays the subsequence from frame 0 (untimed up to `lo`: that builds
@@ -342,9 +371,13 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed form against the CPU oracle")
     ap.add_argument("--legs", default=os.environ.get("DSM_BENCH_LEGS", "all"),
                     help="comma-separated legs beside the headline to run (single_sequence, dropin, fullhd, live, node, kitti_like, "
-                         "streamed, bounded_map); default all")
+                         "streamed, sharded_replay, bounded_map); default all")
+    ap.add_argument("--oracle-replay-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.oracle_replay_worker:
+        oracle_replay_worker(args.oracle_replay_worker)
+        return
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -392,6 +425,20 @@ def main():
     frames_v = frames_all[n_scene * period:n_scene * period + 30] if extras else []
     frames_h = frames_all[n_scene * period + 30:n_scene * period + 40] if extras else []
     rendered_k = [frames_all[n_scene * period + 40 + b * period:n_scene * period + 40 + (b + 1) * period] for b in range(n_scene_k)] if extras else []
+
+    # The checker of the timed region, started now so that it runs beside everything below: the CPU oracle replays one
+    # subsequence per batch from its empty map through the LAST timed frame (a single-threaded replay of (W + K) * F frames
+    # at ~10-15 frames/s: a minute or two, on cores the GPU legs do not use); its maps are compared with the maps the timed
+    # run itself leaves behind -- maps of 300-450 k surfels with the driver's W and K, beyond k_frame_tail's one-workgroup
+    # path -- see "verified" below.  Nothing of it runs inside a timed interval's critical path.
+    total_frames = (W + K) * F
+    n_bat_plan = max(1, min(args.batches, B)) if args.mode == "batched" else 0
+    oracle_jobs, oracle_specs = [], []
+    if rank == 0 and world == 1 and n_bat_plan and not args.no_verify and total_frames <= 1600:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+        oracle_specs = [{"subsequence": g, "camera": "KITTI_1226", "seed": 12345 + 1000 * rank + 17 * scene_of[g], "period": period,
+                         "phase": phase_of[g], "frames": total_frames} for g in range(n_bat_plan)]  # subsequence g = the first of batch g
+        oracle_jobs = start_oracle_replays(oracle_specs)
 
     import torch
     from densesurfelmapping_amd import api
@@ -503,6 +550,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     m_end = [ff.map_size() for ff in handles]
+    # the maps the timed run leaves behind, for the oracle's verdict further down
+    import hashlib
+    end_maps = {}
+    for sp in oracle_specs:
+        got = handles[sp["subsequence"]].map_download()
+        end_maps[sp["subsequence"]] = (int(len(got)), hashlib.sha256(canon_bytes(got)).hexdigest())
 
     # merge of the final clouds (outside the timed region): RCCL all-gather over xGMI
     merged_total = sum(m_end)
@@ -641,6 +694,18 @@ def main():
                                          "launch takes longer (profiles/r04_kernel_trace_batch32x4_default.md)",
                                "note": "the timed region launches every kernel once per batch of subsequences; roofline_single_launch is the "
                                        "same kernel launched for one subsequence"}
+            # the WHOLE frame's algorithmic bytes over the whole frame's kernel time (the launch set
+            # of one batch alone on the GPU), beside the dominant stage's own number -- and which roof actually binds
+            b_alg_b = 9 * n_pix + 60 * n_seed + 88 * mtb + 44 * kb
+            t_frame_b = sum(perb.values()) / nb * 1e-6
+            out["roofline"]["whole_frame_kernel_weighted"] = {
+                "alg_bytes_per_frame": int(b_alg_b), "kernel_us_per_frame": round(t_frame_b * 1e6, 2),
+                "achieved": round(b_alg_b / t_frame_b / 1e9, 1), "unit": "GB/s", "frac": round(b_alg_b / t_frame_b / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "B_alg = 9N + 60S + 88M + 44K of one frame / the sum of its sixteen stages' launch durations per frame"}
+            out["roofline"]["binding_roof"] = "valu_issue"
+            out["roofline"]["binding_roof_note"] = ("the superpixel stages are bound by VALU instruction issue (see `valu_issue`: wave-instructions per "
+                                                    "frame x frames/s against 1 024 SIMDs x clock / 4), not by HBM; `bound`: \"hbm\" names the roof "
+                                                    "`frac` is measured against, as BASELINE.json's metric asks")
             out["batched_kernel_us"] = {k: round(v, 2) for k, v in perb.items()}
             out["batched_kernel_hbm_frac"] = {k: round(nb * stage_alg_bytes(k, n_pix, n_seed, mtb, kb) / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
                                               for k, v in perb.items() if v > 0}
@@ -695,12 +760,16 @@ def main():
         # (surfel_map.cpp:750-789).  The big map is the map of a short 1080p replay replicated
         # with millimetre jitter, so that its surfels project into the frames and take the fusion branch.
         n_h = (cam_h.width // 8) * (cam_h.height // 8)
-        ff = api.FusionFunctions.from_camera(cam_h, device=device, frame_slots=10, surfel_capacity=2_600_000, pipeline_depth=1)
-        for i, (img, dep) in enumerate(frames_h):
-            ff.frame_upload(i, img, dep)
+        plan_h = api.FusionFunctions.pack_replay([t % 10 for t in range(100)], [t // 5 for t in range(100)],
+                                                 np.stack([scene_h.pose(t % 10) for t in range(100)]))
+
+        def handle_h(depth, cap=3_200_000):
+            ff_ = api.FusionFunctions.from_camera(cam_h, device=device, frame_slots=10, surfel_capacity=cap, pipeline_depth=depth)
+            for i, (img, dep) in enumerate(frames_h):
+                ff_.frame_upload(i, img, dep)
+            return ff_
+        ff = handle_h(1)
         ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
-        plan_h = api.FusionFunctions.pack_replay([t % 10 for t in range(60)], [t // 5 for t in range(60)],
-                                                 np.stack([scene_h.pose(t % 10) for t in range(60)]))
         ff.replay_enqueue(plan_h[0][:10], plan_h[1][:10], plan_h[2][:10])
         base = ff.map_download()
         rng = np.random.default_rng(0)
@@ -709,14 +778,27 @@ def main():
             big[f] += rng.normal(scale=1e-3, size=len(big)).astype(np.float32)
         big["update_times"] = 9
         big["last_update"] = 2
-        ff.map_upload(big)
-        ff.replay_enqueue(plan_h[0][10:20], plan_h[1][10:20], plan_h[2][10:20])
-        ff.synchronize()
-        t_h = time.perf_counter()
-        ff.replay_enqueue(plan_h[0][20:40], plan_h[1][20:40], plan_h[2][20:40])
-        ff.synchronize()
-        dt_h = (time.perf_counter() - t_h) / 20
-        st_h, _ = ff.replay_timed(plan_h[0][40:52], plan_h[1][40:52], plan_h[2][40:52])
+        # one 1080p sequence through one handle: strictly serial (depth 1), and with the superpixel stages of G consecutive
+        # frames as one batched launch per kernel while fuse + compaction stay in frame order on the map stream (frame
+        # groups, DESIGN.md section 4: the map is the only thing frame t + 1 needs from frame t, SM.cpp:161)
+        by_depth_h, final_h = {}, {}
+        for depth in (1, 12, 24):
+            fd = ff if depth == 1 else handle_h(depth)
+            fd.map_upload(big)
+            fd.replay_enqueue(plan_h[0][10:34], plan_h[1][10:34], plan_h[2][10:34])
+            fd.synchronize()
+            t_h = time.perf_counter()
+            fd.replay_enqueue(plan_h[0][34:82], plan_h[1][34:82], plan_h[2][34:82])
+            fd.synchronize()
+            by_depth_h[depth] = (time.perf_counter() - t_h) / 48
+            final_h[depth] = fd.map_size()
+            if depth > 1:
+                fd.close()
+        assert len(set(final_h.values())) == 1, final_h  # (same frames, same map: the depth changes nothing in the result)
+        best_h = min(by_depth_h, key=by_depth_h.get)
+        dt_h = by_depth_h[best_h]
+        # per-kernel times: the depth-1 handle, eager replay of the next frames
+        st_h, _ = ff.replay_timed(plan_h[0][82:94], plan_h[1][82:94], plan_h[2][82:94])
         ovh_h = ff.event_overhead_ms * 1e3
         per_h = {k: max(v[0] / max(v[1], 1) * 1e3 - ovh_h, 0.0) for k, v in st_h.items()}
         m_h = ff.timed_mean_local
@@ -728,8 +810,13 @@ def main():
         us_w2 = timed(lambda: ff.map_warp(wp), 50)
         m_w2 = ff.map_size()
         out["fullhd_2M"] = {
-            "workload": "BASELINE configs[4]: 1920x1080 depth stream against a live map of >= 2 M surfels, strictly serial (one stream)",
+            "workload": "BASELINE configs[4]: 1920x1080 depth stream against a live map of >= 2 M surfels, one sequence through one handle",
             "frames_per_s": round(1.0 / dt_h, 1), "ms_per_frame": round(dt_h * 1e3, 3), "live_surfels": round(m_h),
+            "pipeline_depth": best_h,
+            "frames_per_s_by_pipeline_depth": {str(d_): round(1.0 / v, 1) for d_, v in by_depth_h.items()},
+            "pipeline_note": "depth 1 = strictly serial on one stream; 12 / 24 = the superpixel stages of 4 / 8 consecutive frames as one "
+                             "batched launch per kernel (frame groups), fuse + compaction in frame order on the map stream; identical "
+                             "maps (tests/test_gpu_scale.py::test_fullhd_frame_groups)",
             "alg_bytes_per_frame": int(b_h), "e2e_hbm_frac": round(b_h / dt_h / 1e9 / HBM_PEAK_GBS, 4),
             "kernel_us": {k: round(v, 1) for k, v in per_h.items() if k in ("seed_points", "seed_fit", "fuse_surfels", "frame_tail",
                                                                             "update_seeds_0", "assign_0")},
@@ -858,8 +945,33 @@ def main():
             checked.append({"subsequence": b, "batch": g, "surfels": int(len(got)), "oracle_surfels": int(len(lo_)), "equal": bool(same)})
             if not same:
                 bad.append(b)
-        out["verified"] = not bad
-        out["verification"] = {"form": f"{n_bat} batches of {len(groups_b[0])} subsequences in flight at once, one host thread and stream per batch (the timed region's form)",
+        # ... and the timed run ITSELF: the maps it left at the end of the timed region against the oracle replays started
+        # before it (one subsequence per batch, from the empty map through the last timed frame)
+        timed_rows, timed_ok = [], None
+        if oracle_jobs:
+            timed_ok = True
+            t_wait = time.perf_counter()
+            for sp, job in zip(oracle_specs, oracle_jobs):
+                try:
+                    so, _ = job.communicate(timeout=max(5.0, 240.0 - (time.perf_counter() - t_wait)))
+                    rec = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+                except (subprocess.TimeoutExpired, IndexError, ValueError):
+                    job.kill()
+                    rec = None
+                n_gpu, sha_gpu = end_maps[sp["subsequence"]]
+                same = bool(rec) and rec["surfels"] == n_gpu and rec["sha256"] == sha_gpu
+                timed_rows.append({"subsequence": sp["subsequence"], "frames": sp["frames"], "surfels": n_gpu,
+                                   "oracle_surfels": rec["surfels"] if rec else None, "equal": same if rec else None})
+                timed_ok = timed_ok and same
+            oracle_jobs = []
+        out["verified"] = not bad and timed_ok is not False
+        out["verified_timed_region"] = timed_ok
+        out["verification"] = {"timed_region": {"checked": timed_rows,
+                                                "what": "the maps the TIMED run itself left after its last frame (one subsequence per batch, "
+                                                        f"frames 0..{total_frames - 1} from an empty map) against the CPU oracle's replay of the same frames, "
+                                                        "run on host cores beside the GPU legs; NaN-canonical SHA-256 of the whole map"
+                                                        if timed_rows else "skipped (more than 1600 frames per subsequence, or --no-verify)"},
+                               "form": f"{n_bat} batches of {len(groups_b[0])} subsequences in flight at once, one host thread and stream per batch (the timed region's form)",
                                "frames_per_subsequence": n_v, "checked": checked,
                                "against": "oracle/liboracle_port.so (C restatement of fusion_functions.cpp + surfel_map.cpp:1077-1109), NaN-canonical bytes of the whole map"}
         for bt_ in bts:
@@ -945,6 +1057,34 @@ def main():
             h_.close()
         for pf in pins:
             pf.close()
+
+    if leg_on("sharded_replay"):
+        # BASELINE configs[2]'s own driver on one rank (densesurfelmapping_amd/replay.py: what every rank of
+        # `python -m densesurfelmapping_amd.replay --gpus G` runs on its shard): ONE sequence through one handle at pipeline
+        # depth 24, frames streamed from page-locked host memory in chunks of 48 beside the kernels of the chunk before.
+        # Pre-rendered synthetic frames, so that the engine is measured and not numpy: once with the source's frames
+        # already page-locked (no host copy at all), once through the prefetch thread that copies every frame into the
+        # engine's page-locked blocks (what a decoded KITTI log goes through).
+        from densesurfelmapping_amd import replay as rp
+        n_w, n_t = 480, 2880
+        res = {}
+        for label in ("page_locked_source", "prefetch_thread_copy"):
+            src = rp.SyntheticSource(n_w + n_t, camera="KITTI_1226", seed=12345, prerender=True)
+            if label == "prefetch_thread_copy":
+                src.pinned_run = None  # (the generic path: frames() only)
+            eng = rp.HipEngine(cam, device=device, capacity=capacity, pipeline_depth=24, chunk=48)
+            eng.replay(src, 0, n_w)
+            eng.replay(src, n_w, n_w + n_t)
+            st = eng.stats
+            res[label] = {"frames_per_s": round(st["frames"] / st["seconds"], 1),
+                          "host_to_device_GBps": round(st["frames"] * st["bytes_per_frame"] / st["seconds"] / 1e9, 2),
+                          "final_surfels": eng.ff.map_size()}
+            eng.close()
+            src.close()
+        out["sharded_replay"] = {"value": res["page_locked_source"]["frames_per_s"], "unit": "frames/s per rank", "frames": n_t,
+                                 "pipeline_depth": 24, "chunk_frames": 48, **res,
+                                 "note": "one rank of BASELINE configs[2] (replay.HipEngine.replay): dsm_frames_upload_async of chunk k+1, then "
+                                         "dsm_replay_enqueue of chunk k; parity per shard: tests/test_gpu_parity.py::test_sharded_replay_*"}
 
     if leg_on("kitti_like") and args.mode == "batched":
         # The reference's REAL input distribution through the timed form: the same batched replay on frames
@@ -1083,6 +1223,8 @@ def main():
         out["valu_issue"] = valu_issue(fps / world, clock.ghz())
         out["clocks"] = clock.other()
 
+    for job in oracle_jobs:  # (the verification block did not run: e.g. --mode streams)
+        job.kill()
     if rank == 0:
         print(json.dumps(out))
     for ff in handles:

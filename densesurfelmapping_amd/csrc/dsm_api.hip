@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <new>
 #include <algorithm>
 #include <atomic>
@@ -16,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "dsm_device.h"
@@ -36,9 +38,13 @@ hipError_t batch_streams_reserve(int device); // see BatchStreamPool
 hipStream_t batch_stream_at(int device, int i);
 constexpr int kUploadStreams = 2;
 hipStream_t device_upload_stream(int device, int *which); // asynchronous frame uploads of the handles on the device (dsm_frame_upload_async)
-constexpr uint64_t kBatchBit = 1ull << 62;    // up_pending: a batch stream has not waited for this handle's latest upload yet
+constexpr uint64_t kBatchBit = 1ull << 62;    // UpEntry::pending: a batch stream has not waited for this upload of the handle yet
 
 } // namespace
+
+// the handles alive in this process: dsm_batch_destroy gives a handle back its freedom only if it still exists
+static std::mutex g_live_mu;
+static std::unordered_set<dsm_handle *> g_live;
 
 // A few host threads for the drop-in calls' bulk copies (frame rows into page-locked staging, the caller's surfel
 // array against / into / out of its page-locked shadow): one core moves ~15 GB/s, the copies of a 100 k-surfel map
@@ -167,11 +173,24 @@ struct dsm_handle {
     // of its throughput): uploads that follow one wait for ev_fence, recorded once behind the batch
     hipEvent_t ev_fence = nullptr;
     bool fence_pending = false;
-    // dsm_frame_upload_async: ev_up = this handle's latest asynchronous upload has landed (recorded on the device's upload
-    // stream); up_pending = which consumers have not been ordered behind it yet (bit p: pipeline p, kSerialBit: the map
-    // stream, kBatchBit: a batch stream)
-    hipEvent_t ev_up = nullptr;
-    uint64_t up_pending = 0;
+    // dsm_frame(s)_upload_async: the last kUpRing asynchronous uploads of this handle, oldest first.  ev = the upload has
+    // landed (recorded on the device's upload stream the handle was dealt: ONE stream, so an entry's event covers every
+    // entry before it); [lo, hi) = the frame slots it wrote; pending = which consumers have not been ordered behind it
+    // yet (bit p: pipeline p, kSerialBit: the map stream, kBatchBit: a batch stream).  A consumer waits for the NEWEST
+    // upload that wrote a slot it reads -- not for the latest upload whatever it wrote: in the double-buffered pattern
+    // (send chunk k+1, then enqueue chunk k) chunk k waits for upload k, and upload k+1 -- ordered behind chunk k-1, whose
+    // slots it overwrites -- runs beside chunk k's kernels.  (Until round 5 there was one event, re-recorded by every
+    // upload: chunk k waited for upload k+1, which waited for chunk k-1 -- a handle streaming alone had no overlap at all.)
+    struct UpEntry {
+        hipEvent_t ev = nullptr;
+        int lo = 0, hi = 0;
+        uint64_t pending = 0;
+    };
+    static constexpr int kUpRing = 4;
+    UpEntry up_ring[kUpRing];
+    int up_n = 0;
+    // the frame slots the frames being submitted read (set by the enqueue calls that know them; everything otherwise)
+    int read_lo = 0, read_hi = INT32_MAX;
     int up_which = -1; // which of the device's upload streams this handle's uploads take (dealt out at its first upload)
     int64_t frames_submitted = 0, frames_done = 0;
     int batches_joined = 0; // dsm_batch_create copied this handle's context: it must not change any more
@@ -290,14 +309,33 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
     return DSM_OK;
 }
 
-// Order `st` behind this handle's latest asynchronous frame upload, once per consumer (`bits` = the consumer's bits of
-// up_pending, see dsm_handle).
+// Order `st` behind the asynchronous frame uploads that wrote a slot in [h->read_lo, h->read_hi), once per consumer
+// (`bits` = the consumer's bits of UpEntry::pending, see dsm_handle): the newest such upload's event covers the older ones.
 int wait_uploads(dsm_handle *h, hipStream_t st, uint64_t bits) {
-    if (!(h->up_pending & bits)) return DSM_OK;
-    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_up, 0));
-    h->up_pending &= ~bits;
+    for (int i = h->up_n - 1; i >= 0; i--) {
+        dsm_handle::UpEntry &e = h->up_ring[i];
+        if (!(e.pending & bits) || e.lo >= h->read_hi || h->read_lo >= e.hi) continue;
+        HIP_TRY(h, hipStreamWaitEvent(st, e.ev, 0));
+        for (int k = 0; k <= i; k++) h->up_ring[k].pending &= ~bits;
+        break;
+    }
     return DSM_OK;
 }
+// [lo, hi) of n slot indices
+void slot_range(const int32_t *slots, int n, int *lo, int *hi) {
+    int a = INT32_MAX, b = 0;
+    for (int i = 0; i < n; i++) {
+        a = slots[i] < a ? slots[i] : a;
+        b = slots[i] + 1 > b ? slots[i] + 1 : b;
+    }
+    *lo = n > 0 ? a : 0;
+    *hi = n > 0 ? b : 0;
+}
+struct ReadSlots { // the slots an enqueue call reads, for the lifetime of the call
+    dsm_handle *h;
+    ReadSlots(dsm_handle *h_, int lo, int hi) : h(h_) { h->read_lo = lo; h->read_hi = hi; }
+    ~ReadSlots() { h->read_lo = 0; h->read_hi = INT32_MAX; }
+};
 
 int fuse_grid_bound(const dsm_handle *h) { return h->hc.cap; }
 
@@ -467,7 +505,9 @@ int submit_group(dsm_handle *h) {
         HIP_TRY(h, hipStreamWaitEvent(lead.stream, h->ev_params, 0));
         h->params_pending &= ~mask;
     }
-    if (int rc = wait_uploads(h, lead.stream, mask)) return rc; // (the same argument as for the params: only `lead` reads these frames' slots before the map stream does)
+    // (only `lead` reads these frames' slots before the map stream does -- which waits for lead.ev_sp below -- and only the
+    // lead stream's bit is cleared: a later frame-by-frame submit on another of these pipelines waits for itself)
+    if (int rc = wait_uploads(h, lead.stream, 1ull << half)) return rc;
     if (!h->g_group[half]) {
         const std::string err = capture_graph([&](hipStream_t st) {
             return launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, st, nullptr, 0, kLastSuperpixelStage, h->d_pipe_ctxs + p0, G);
@@ -923,12 +963,20 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     (void)rc;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.insert(h);
+    }
     *out = h;
     return DSM_OK;
 }
 
 void dsm_destroy(dsm_handle *h) {
     if (!h) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(h);
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 4; i++) {
@@ -953,7 +1001,10 @@ void dsm_destroy(dsm_handle *h) {
     for (hipEvent_t e : h->ev_slot)
         if (e) (void)hipEventDestroy(e);
     if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
-    if (h->ev_up) { (void)hipEventSynchronize(h->ev_up); (void)hipEventDestroy(h->ev_up); }
+    for (int i = h->up_n - 1; i >= 0; i--) {
+        if (i == h->up_n - 1) (void)hipEventSynchronize(h->up_ring[i].ev);
+        (void)hipEventDestroy(h->up_ring[i].ev);
+    }
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
@@ -1360,7 +1411,6 @@ int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *imag
     if (rc) return rc;
     hipStream_t up = device_upload_stream(h->device, &h->up_which);
     if (!up) return fail(h, DSM_E_HIP, "no upload stream on device %d", h->device);
-    if (!h->ev_up) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
     // behind every frame enqueued so far for this handle (its map stream runs fuse + tail of every frame after the
     // superpixel stages that read the slots, and waits for the batches the handle takes part in): they may read these slots
     HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
@@ -1391,17 +1441,37 @@ int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *imag
             else HIP_TRY(h, hipMemcpy2DAsync(dd + (size_t)i * plane, (size_t)pitch * 4, src, depth_step, (size_t)w * 4, (size_t)hh, hipMemcpyHostToDevice, up));
         }
     }
-    HIP_TRY(h, hipEventRecord(h->ev_up, up));
-    h->up_pending = ~0ull;
+    // a ring entry for this upload; when the ring is full the oldest entry is folded into the one after it (whose event
+    // is later on the same stream: waiting for it instead is safe) and its event is reused
+    hipEvent_t ev = nullptr;
+    if (h->up_n == dsm_handle::kUpRing) {
+        dsm_handle::UpEntry old = h->up_ring[0];
+        for (int i = 1; i < h->up_n; i++) h->up_ring[i - 1] = h->up_ring[i];
+        h->up_n--;
+        dsm_handle::UpEntry &nx = h->up_ring[0];
+        if (old.pending) {
+            nx.lo = old.lo < nx.lo ? old.lo : nx.lo;
+            nx.hi = old.hi > nx.hi ? old.hi : nx.hi;
+            nx.pending |= old.pending;
+        }
+        ev = old.ev;
+    }
+    if (!ev) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    dsm_handle::UpEntry &e = h->up_ring[h->up_n++];
+    e.ev = ev;
+    e.lo = slot0;
+    e.hi = slot0 + n;
+    e.pending = ~0ull;
+    HIP_TRY(h, hipEventRecord(e.ev, up));
     return DSM_OK;
 }
 
 int dsm_frame_uploads_wait(dsm_handle *h) {
     if (!h) return DSM_E_INVALID;
-    if (!h->ev_up) return DSM_OK;
+    if (!h->up_n) return DSM_OK;
     int rc = bind_device(h);
     if (rc) return rc;
-    HIP_TRY(h, hipEventSynchronize(h->ev_up));
+    HIP_TRY(h, hipEventSynchronize(h->up_ring[h->up_n - 1].ev));
     return DSM_OK;
 }
 
@@ -1415,6 +1485,7 @@ int dsm_fuse_frame_resident_inv(dsm_handle *h, int slot, int reference_frame_ind
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
     int rc = bind_device(h);
     if (rc) return rc;
+    const ReadSlots reads(h, slot, slot + 1);
     if ((rc = stage_params(h, slot, reference_frame_index, pose16, inv_pose16))) return rc;
     if ((rc = submit_frame(h, true))) return rc;
     if (!h->own_up_stream) return DSM_OK;
@@ -1436,6 +1507,9 @@ int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const
     if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
     int rc = bind_device(h);
     if (rc) return rc;
+    int r_lo, r_hi;
+    slot_range(slots, n, &r_lo, &r_hi);
+    const ReadSlots reads(h, r_lo, r_hi);
     for (int i = 0; i < n;) {
         int m = 0;
         if ((rc = stage_params_batch(h, n - i, slots + i, ref_idx + i, poses16 + 16 * (size_t)i,
@@ -1727,9 +1801,11 @@ int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots,
         if (staged != m) return bfail(b, DSM_E_STATE, "handle %zu: parameter rings of the batch are out of step", j);
         BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
         BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
-        if (h->up_pending & kBatchBit) { // frames this handle was sent with dsm_frame_upload_async
-            BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_up, 0));
-            h->up_pending &= ~kBatchBit;
+        if (h->up_n) { // frames this handle was sent with dsm_frame(s)_upload_async: the uploads that wrote the slots these frames read
+            int r_lo, r_hi;
+            slot_range(slots + o, m, &r_lo, &r_hi);
+            const ReadSlots reads(h, r_lo, r_hi);
+            if (wait_uploads(h, b->stream, kBatchBit)) return bfail(b, DSM_E_HIP, "handle %zu: %s", j, h->err.c_str());
         }
     }
     return DSM_OK;
@@ -1821,6 +1897,11 @@ int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
 
 void dsm_batch_destroy(dsm_batch *b) {
     if (!b) return;
+    { // the batch's copy of the handles' contexts goes with it (a handle destroyed before its batch is simply skipped)
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (dsm_handle *h : b->hs)
+            if (g_live.count(h) && h->batches_joined > 0) h->batches_joined--;
+    }
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     if (b->graph) (void)hipGraphExecDestroy(b->graph);

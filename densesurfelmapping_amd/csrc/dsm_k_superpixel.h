@@ -437,7 +437,7 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
         wave_lds_sync();
         md = ordered_sum(dl, nd) / (float)nd;
         stamp(c, sweep, s, 4, lane);
-        md = huber_passes_wave(dl, lt, nd, md, 0, c->huber, lane);
+        if (!mean_depth_is_settled(md)) md = huber_passes_wave(dl, lt, nd, md, 0, c->huber, lane);
     }
     stamp(c, sweep, s, 5, lane);
     if (c->stamps && lane == 0) c->stamps[((int64_t)sweep * c->n_seed + s) * 8 + 7] = nd;
@@ -768,7 +768,9 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     const int nd = (int)((tail - lane4) >> 8);
     const bool empty = stats && cnt == 0;
     if (empty) atomicMin(&c->first_empty[sweep * kWorkers + chunk_of(S, s)], s); // FF.cpp:516-517: the worker returns, abandoning the rest of its chunk
-    const bool over = stats && nd >= CAP;
+    // (a list with a +inf depth needs no pass and no complete list: its robust mean is +inf, dsm_math.h mean_depth_is_settled)
+    const bool settled = sum == __builtin_inff();
+    const bool over = stats && nd >= CAP && !settled;
     const bool fin = stats && cnt > 0 && !over;
     int acc_x = 0;
 #pragma unroll
@@ -781,6 +783,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
     float md = 0.0f;
     bool run = fin && nd > 0;
     if (run) md = sum / (float)nd;
+    run = run && !settled;
     const double hr = c->huber;
     wave_lds_sync();
     // ---- the FIRST Huber-Newton pass of all 64 seeds, one chain per lane.  87 % of all seeds are done after it
@@ -825,7 +828,7 @@ template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds(const
 // queued seeds, 64 to a wave, one chain per lane over the lists in rest_list (coalesced: 64 lanes read 64 consecutive
 // floats per element).  The workgroups after them: seeds whose list did not fit an LDS row, gathered and refined from
 // scratch by one wave each.
-constexpr int kRestOverBlocks = 32;
+constexpr int kRestOverBlocks = 128; // (32 until round 5: on the reference's kind of input hundreds of seeds per frame outgrow their LDS row, see kFitLargeBlocks)
 constexpr int kLaneBatch = 8; // handles per launch from which the lane-per-seed kernels are used (launch_frame)
 template <bool BATCH> __global__ __launch_bounds__(64) void k_update_seeds_rest(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();

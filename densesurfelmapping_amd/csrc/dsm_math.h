@@ -273,9 +273,18 @@ DSM_HD int pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh
 // same bits as the double divide and the cast, at a third of the instructions.
 DSM_HD float huber_newton_step(float a, float b) { return (-a) / (b + 10.0f); }
 
+// A seed with a +inf member depth (the reference's feed has them: depth = bf / disparity with disparity 0,
+// kitti_publisher/scripts/publisher.py:40) starts from md = +inf, and so does one whose sum overflowed.  Every residual
+// inf - d is then +inf (d finite) or NaN (d = +inf): no element is in the Huber core, a = a finite multiple of hr, b = 0,
+// delta = -a / 10 is finite and md + delta = +inf again -- whether the loop leaves after one pass or five, the result is
+// the +inf it started from.  (The list holds depths > 0.1 only: the sum is never NaN, and never -inf.)  The passes are
+// skipped; tests/hostemu.cpp runs this against the reference's loop.
+DSM_HD bool mean_depth_is_settled(float md) { return md == __builtin_inff(); }
+
 DSM_HD float huber_mean_depth(const float *list, int n, float sum, double huber) {
     const float hr_above = flt_above(huber);
     float md = sum / (float)n;
+    if (mean_depth_is_settled(md)) return md;
     for (int it = 0; it < 5; it++) {
         float a = 0, b = 0;
         for (int k = 0; k < n; k++) {

@@ -3,8 +3,9 @@
 The per-frame path has a strict temporal dependency (frame t+1 fuses into the map frame t produced,
 surfel_map.cpp:161), so a single sequence does not shard; independent subsequences do (SURVEY.md
 §8(e)).  Each rank owns one GPU and one handle, replays its contiguous subsequence with keyframe
-indices restarting at 0 -- frames arrive from the host, double-buffered through two frame slots, the
-map never leaves HBM -- and the final clouds are merged with one all-gather of the counts and one
+indices restarting at 0 -- frames arrive from page-locked host memory in chunks whose transfers run beside the
+kernels of the chunk before, through the library's one-sequence fast path (frame groups), the map never leaves HBM --
+and the final clouds are merged with one all-gather of the counts and one
 all-gather of the padded clouds (RCCL over xGMI when the backend is "nccl"; the same code runs on
 "gloo" with CPU tensors in the tests).  There is no collective on the per-frame path.
 
@@ -17,7 +18,7 @@ kitti_publisher/scripts/publisher.py:31-41) and a KITTI-format pose file (denses
 ranks itself (torch.distributed.run on 127.0.0.1) after checking that G devices are visible.  Parity of a sharded run
 is per subsequence: rank r's map is the reference's map of frames [a_r, b_r) fused from an empty map with keyframe
 indices restarting at 0 -- NOT a slice of the one-sequence map (surfels seen on both sides of a cut are not fused
-across it); tests/test_cpu.py::test_sharded_replay_gloo_world2 and tests/test_gpu_parity.py::test_sharded_replay_*
+across it); tests/test_cpu.py::test_sharded_replay_gloo and tests/test_gpu_parity.py::test_sharded_replay_*
 check exactly that, and that the merged cloud is the concatenation of the shards in rank order.
 """
 from __future__ import annotations
@@ -79,19 +80,52 @@ def merge_clouds(local_cloud, group=None):
 
 # ---------------------------------------------------------------------------------------------- frame sources
 class SyntheticSource:
-    """The synthetic drive of SURVEY.md §8(d) (densesurfelmapping_amd/synth.py): frame t of the one long sequence."""
+    """The synthetic drive of SURVEY.md §8(d) (densesurfelmapping_amd/synth.py): frame t of the one long sequence.
+    prerender=True renders the scene's period once, on worker processes (synth.render_many); the engine then keeps it in
+    page-locked memory laid out like its frame slots (`pinned_run`) and a replay moves no frame on the host."""
 
-    def __init__(self, n_frames, camera="KITTI_1226", seed=12345):
+    def __init__(self, n_frames, camera="KITTI_1226", seed=12345, prerender=False):
         from . import synth
         self.cam = getattr(synth, camera)
         self.scene = synth.Scene(seed=seed)
         self.n_frames = n_frames
+        self._period = None
+        self._pinned = None
+        if prerender:
+            per = self.scene.frames_per_period
+            self._period = synth.render_many([(self.cam, self.scene, i) for i in range(min(per, n_frames))])
 
     def frames(self, a, b):
         """(image uint8 [H,W], depth float32 [H,W], pose 4x4 cam->world) of frames a .. b-1"""
         from . import synth
+        if self._period is not None:
+            for t in range(a, b):
+                image, depth = self._period[t % len(self._period)]
+                yield image, depth, self.scene.pose(t)
+            return
         for t, image, depth, pose, _ in synth.sequence(self.cam, self.scene, b - a, start=a):
             yield image, depth, pose
+
+    def pose(self, t):
+        return self.scene.pose(t)
+
+    def pinned_run(self, api, t, n_max):
+        """frames t .. t+n-1 (n <= n_max) as a run of a page-locked block in slot layout: (block, first, n), or None when
+        the source holds no pre-rendered frames.  The block is two periods back to back, so that a run may cross the end
+        of a period; a run never exceeds one period."""
+        if self._period is None:
+            return None
+        per = len(self._period)
+        if self._pinned is None:
+            self._pinned = api.PinnedFrames((self.cam.height, self.cam.width), 2 * per)
+            for i in range(2 * per):
+                self._pinned.set(i, *self._period[i % per])
+        return self._pinned, t % per, min(n_max, per)
+
+    def close(self):
+        if self._pinned is not None:
+            self._pinned.close()
+            self._pinned = None
 
 
 class KittiSource:
@@ -122,23 +156,118 @@ class KittiSource:
 
 # ---------------------------------------------------------------------------------------------- the engine
 class HipEngine:
-    """One handle of the HIP engine (include/dsm.h) with a resident map: frames go up through two slots in turn on the
-    handle's upload stream while the previous frame is being fused.  There is no other engine in this package: without
-    a gfx950 device the constructor raises (DSM_E_NO_DEVICE)."""
+    """One handle of the HIP engine (include/dsm.h) with a resident map, driven the way the library is fastest for ONE
+    sequence: frame groups (pipeline depth 24: the superpixel stages of eight consecutive frames per batched launch, fuse
+    + compaction in frame order on the map stream) and frames streamed from page-locked host memory in chunks --
+    dsm_frames_upload_async for chunk k+1, then dsm_replay_enqueue for chunk k, so that the transfer of one chunk runs
+    beside the kernels of the one before (two halves of 2 x chunk frame slots).  Frames reach the page-locked blocks on a
+    prefetch thread (decode / render / copy) unless the source already keeps them there (`pinned_run`).  `fuse` is the
+    frame-at-a-time form of the same thing (SurfelMap::fuse_map, surfel_map.cpp:1060-1113).  There is no other engine in this package:
+    without a gfx950 device the constructor raises (DSM_E_NO_DEVICE)."""
 
-    def __init__(self, cam, device=0, capacity=0):
+    def __init__(self, cam, device=0, capacity=0, pipeline_depth=24, chunk=48):
         from . import api
         self._api = api
-        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=2, surfel_capacity=capacity,
-                                                  flags=api.DSM_FLAG_UPLOAD_STREAM, pipeline_depth=1)
+        self.chunk = max(1, int(chunk))
+        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=2 * self.chunk, surfel_capacity=capacity,
+                                                  pipeline_depth=pipeline_depth)
         self.ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
         self.n = 0
+        self._pins = None
+        self.stats = {}
 
-    def fuse(self, image, depth, pose, ref_idx):  # SurfelMap::fuse_map (surfel_map.cpp:1060-1113) against the resident map
-        slot = self.n & 1
+    def fuse(self, image, depth, pose, ref_idx):  # one frame: blocking upload into a slot, one enqueue
+        slot = self.n % (2 * self.chunk)
         self.ff.frame_upload(slot, image, depth)
         self.ff.fuse_frame_resident(slot, ref_idx, pose)
         self.n += 1
+
+    def replay(self, source, a, b, keyframe_every=KEYFRAME_EVERY):
+        """frames [a, b) of `source`, keyframe indices restarting at 0, streamed in chunks (see the class comment)"""
+        import queue
+        import threading
+        api, ff, C = self._api, self.ff, self.chunk
+        n_total = b - a
+        chunks = [(a + c0, min(C, n_total - c0)) for c0 in range(0, n_total, C)]  # (first frame, frames)
+        zero_copy = getattr(source, "pinned_run", None) is not None and source.pinned_run(api, a, 1) is not None
+        ready = queue.Queue()
+        free = threading.Semaphore(3)
+        stop = threading.Event()
+        if not zero_copy and self._pins is None:
+            self._pins = [api.PinnedFrames(ff, C) for _ in range(3)]
+
+        def produce():  # decode / render / copy chunk k into page-locked block k mod 3, as soon as that block is free
+            try:
+                for k, (t0, n) in enumerate(chunks):
+                    free.acquire()
+                    if stop.is_set():
+                        return
+                    pf = self._pins[k % 3]
+                    poses = []
+                    for i, (image, depth, pose) in enumerate(source.frames(t0, t0 + n)):
+                        pf.set(i, image, depth)
+                        poses.append(pose)
+                    ready.put((k, poses, None))
+                ready.put(None)
+            except BaseException as e:  # noqa: BLE001 -- handed to the consumer
+                ready.put((None, None, e))
+
+        def send(k, half):  # chunk k -> slot half `half`
+            t0, n = chunks[k]
+            if zero_copy:
+                i = 0
+                while i < n:  # runs of the source's page-locked block (a run ends where its period does)
+                    pf, first, m = source.pinned_run(api, t0 + i, n - i)
+                    ff.frames_upload_async(half * C + i, pf, first, m)
+                    i += m
+            else:
+                ff.frames_upload_async(half * C, self._pins[k % 3], 0, n)
+
+        th = None
+        if not zero_copy:
+            th = threading.Thread(target=produce, daemon=True)
+            th.start()
+        t_start = time.perf_counter()
+        poses_of = {}
+
+        def take(k):  # wait until chunk k's frames are in page-locked memory; their poses
+            if zero_copy:
+                t0, n = chunks[k]
+                poses_of[k] = [source.pose(t) for t in range(t0, t0 + n)]
+                return
+            item = ready.get()
+            if item is None or item[2] is not None:
+                raise item[2] if item else RuntimeError("frame source ended early")
+            poses_of[item[0]] = item[1]
+
+        try:
+            if chunks:
+                take(0)
+                send(0, 0)
+            for k, (t0, n) in enumerate(chunks):
+                if k + 1 < len(chunks):
+                    take(k + 1)
+                    send(k + 1, (k + 1) & 1)  # BEFORE chunk k is enqueued: ordered behind chunk k - 1, whose slots it overwrites
+                half = k & 1
+                slots = [half * C + i for i in range(n)]
+                refs = [(t0 - a + i) // keyframe_every for i in range(n)]
+                ff.replay_enqueue(*ff.pack_replay(slots, refs, np.stack(poses_of.pop(k))))
+                if not zero_copy:
+                    # page-locked blocks may be refilled once their transfers have landed: the newest upload is chunk
+                    # k + 1's, behind chunk k - 1's kernels -- the device still holds chunk k's while the host waits
+                    ff.frame_uploads_wait()
+                    free.release()
+            ff.synchronize()
+        finally:
+            stop.set()
+            free.release()
+            if th is not None:
+                th.join(timeout=60)
+        self.n += n_total
+        dt = time.perf_counter() - t_start
+        self.stats = {"frames": n_total, "seconds": dt, "chunk_frames": C, "zero_copy": bool(zero_copy),
+                      "bytes_per_frame": int(ff.frame_pitch() * ff.height * 5)}
+        return n_total
 
     def cloud(self):
         """the final map as a numpy array of 44-byte records (synchronises)"""
@@ -152,23 +281,30 @@ class HipEngine:
         return t[: got * SURFEL_BYTES]
 
     def close(self):
+        self.ff.frame_uploads_wait()
         self.ff.close()
+        for pf in self._pins or []:
+            pf.close()
+        self._pins = None
 
 
 def replay_shard(engine, source, a, b, keyframe_every=KEYFRAME_EVERY):
     """Frames [a, b) of `source` through `engine`, keyframe indices restarting at 0."""
+    if hasattr(engine, "replay"):  # the HIP engine streams the shard in chunks
+        return engine.replay(source, a, b, keyframe_every)
     for k, (image, depth, pose) in enumerate(source.frames(a, b)):
         engine.fuse(image, depth, pose, k // keyframe_every)
     return b - a
 
 
-def run_rank(source, rank, world, *, engine_factory=None, backend="nccl", device=0, save_shards=None, out=None, group=None):
+def run_rank(source, rank, world, *, engine_factory=None, backend="nccl", device=0, save_shards=None, out=None, group=None,
+             engine_options=None):
     """What one rank of a sharded replay does; returns the summary (rank 0's carries the merged cloud's digest).
     engine_factory(cam) -> engine: the tests' CPU stand-in goes in here; the default is the HIP engine."""
     import torch
     shards = shard_subsequences(source.n_frames, world)
     a, b = shards[rank]
-    engine = engine_factory(source.cam) if engine_factory else HipEngine(source.cam, device=device)
+    engine = engine_factory(source.cam) if engine_factory else HipEngine(source.cam, device=device, **(engine_options or {}))
     t0 = time.perf_counter()
     n = replay_shard(engine, source, a, b)
     on_device = backend == "nccl" and hasattr(engine, "cloud_tensor")
@@ -188,10 +324,17 @@ def run_rank(source, rank, world, *, engine_factory=None, backend="nccl", device
         merged, counts = cloud, [cloud.numel() // SURFEL_BYTES]
     merged_np = merged.cpu().numpy()
     t_merge = time.perf_counter() - t1
+    stream_stats = dict(getattr(engine, "stats", None) or {})
     if hasattr(engine, "close"):
         engine.close()
+    if hasattr(source, "close"):
+        source.close()
     summary = {"rank": rank, "world": world, "frames": [a, b], "replayed": n, "surfels": counts[rank], "replay_s": round(t_replay, 3),
                "frames_per_s": round(n / t_replay, 1) if t_replay > 0 else None, "merge_s": round(t_merge, 4), "backend": backend if world > 1 else None}
+    if stream_stats.get("seconds"):  # the streamed replay alone (without the final download of the cloud)
+        summary["streamed"] = {"frames_per_s": round(stream_stats["frames"] / stream_stats["seconds"], 1),
+                               "host_to_device_GBps": round(stream_stats["frames"] * stream_stats["bytes_per_frame"] / stream_stats["seconds"] / 1e9, 2),
+                               "chunk_frames": stream_stats["chunk_frames"], "frames_already_page_locked": stream_stats["zero_copy"]}
     if rank == 0:
         summary.update({"shards": [list(s) for s in shards], "counts": counts, "merged_surfels": int(merged_np.size // SURFEL_BYTES),
                         "merged_sha256": hashlib.sha256(merged_np.tobytes()).hexdigest()})
@@ -229,6 +372,9 @@ def main(argv=None):
     ap.add_argument("--frames", type=int, help="use only the first N frames of the KITTI sequence")
     ap.add_argument("--camera", default="KITTI_1226", help="synthetic camera (densesurfelmapping_amd.synth)")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--prerender", action="store_true", help="synthetic: render the scene's period up front and keep it page-locked (a replay then measures the engine, not numpy)")
+    ap.add_argument("--pipeline-depth", type=int, default=24, help="frames of the sequence in flight (frame groups; 1 = strictly serial)")
+    ap.add_argument("--chunk", type=int, default=48, help="frames per host-to-device transfer")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI; gloo moves the clouds through host memory")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (a one-GPU box; needs --backend gloo)")
@@ -247,7 +393,7 @@ def main(argv=None):
     if world != args.gpus:
         sys.exit(f"replay: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     device = 0 if (world == 1 or args.one_device) else int(os.environ.get("LOCAL_RANK", "0"))
-    source = KittiSource(args.kitti, args.poses, args.bf, args.frames) if args.kitti else SyntheticSource(args.synthetic, args.camera, args.seed)
+    source = KittiSource(args.kitti, args.poses, args.bf, args.frames) if args.kitti else SyntheticSource(args.synthetic, args.camera, args.seed, prerender=args.prerender)
     import torch
     torch.cuda.set_device(device)
     if world > 1:
@@ -256,7 +402,8 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
-    summary = run_rank(source, rank, world, backend=args.backend, device=device, save_shards=args.save_shards, out=args.out)
+    summary = run_rank(source, rank, world, backend=args.backend, device=device, save_shards=args.save_shards, out=args.out,
+                       engine_options={"pipeline_depth": args.pipeline_depth, "chunk": args.chunk})
     if world > 1:
         rows = [None] * world
         dist.all_gather_object(rows, summary)
@@ -265,7 +412,7 @@ def main(argv=None):
         rows = [summary]
     if rank == 0:
         head = dict(rows[0])
-        head["per_rank"] = [{k: r[k] for k in ("rank", "frames", "surfels", "replay_s", "frames_per_s")} for r in rows]
+        head["per_rank"] = [{k: r.get(k) for k in ("rank", "frames", "surfels", "replay_s", "frames_per_s", "streamed")} for r in rows]
         head["frames_per_s_all_ranks"] = round(sum(r["replayed"] for r in rows) / max(r["replay_s"] for r in rows), 1)
         print(json.dumps(head))
 

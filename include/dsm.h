@@ -220,9 +220,10 @@ int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size
 /* ---- streamed input: frames of a replay arrive from host memory while earlier frames are being fused (the reference
  * receives every frame through image_input / depth_input, surfel_map.cpp:83-101).  dsm_frame_upload_async returns at once:
  * the copy runs on the device's upload stream, ordered behind every frame enqueued so far for this handle (which may
- * still read the slot), and every frame enqueued AFTER the call -- alone or through a batch -- waits for it.  So a
- * replay double-buffers in chunks: upload chunk k+1 into the slots chunk k-1 used, THEN enqueue chunk k; the uploads
- * overlap the kernels of chunk k.  The source must be page-locked (dsm_host_alloc) and stay untouched until
+ * still read the slot), and a frame enqueued AFTER the call -- alone or through a batch -- waits for it if it reads one of
+ * the slots it writes (the library keeps the last four uploads of a handle apart by slot range; older ones count as
+ * one).  So a replay double-buffers in chunks: upload chunk k+1 into the slots chunk k-1 used, THEN enqueue chunk k --
+ * chunk k waits for upload k only, and upload k+1 runs beside its kernels.  The source must be page-locked (dsm_host_alloc) and stay untouched until
  * dsm_frame_uploads_wait (or dsm_synchronize after a frame that reads the slot).  Rows laid out with the slot pitch
  * (dsm_frame_pitch elements per row: img_step = pitch, depth_step = 4 * pitch; the pad columns are never read) go up
  * as one transfer per plane, any other step row by row. ---- */
@@ -279,8 +280,16 @@ int dsm_seed_count(const dsm_handle *h);
 /* ---- state-level test taps (poke superpixel state, run single stages) ------------------
  * Stage indices are positions in the frame's kernel sequence: 0 init_seeds, 1 assign_0, 2 update_seeds_0,
  * 3 commit_seeds_0, 4 assign_1, 5 resolve_1, 6 update_seeds_1, 7 commit_seeds_1, 8 assign_2, 9 resolve_2,
- * 10 update_seeds_2, 11 commit_seeds_2, 12 seed_points, 13 seed_fit, 14 fuse_surfels, 15 frame_tail.  The label image is
- * updated in place from sweep to sweep (ABI 3; `which` = 0 or 1 names the same buffer: the sweeps used to take turns). */
+ * 10 update_seeds_2, 11 commit_seeds_2, 12 seed_points, 13 seed_fit, 14 fuse_surfels, 15 frame_tail.
+ * ABI 3 notes for users of these taps:
+ *  - there is ONE label image, updated in place from sweep to sweep; `which` = 0 and 1 both name it (the sweeps used to take
+ *    turns between two buffers, and old callers pass `sweep & 1`);
+ *  - a sweep >= 1 is the PAIR assign_k + resolve_k (stages 4-5 and 8-9): assign leaves its picks in a side plane and
+ *    resolve rewrites the label image from them.  Re-running assign_k alone after its resolve_k reads the already updated
+ *    image and does not reproduce the sweep: inject the pre-sweep image (dsm_debug_set_label_buffer) and run the pair;
+ *  - dsm_debug_set_label_buffer checks the image: every entry a superpixel index of this grid, and -1 exactly at the pixels
+ *    beyond every cell's reach (image sizes with (size mod 8) > 4), where the assignment stage itself writes -1 --
+ *    DSM_E_INVALID otherwise (the kernels index per-seed arrays with the labels they read). */
 int dsm_debug_run_stages(dsm_handle *h, int slot, int reference_frame_index, const float *pose16, int first_stage,
                          int last_stage);
 int dsm_debug_get_label_buffer(dsm_handle *h, int which, int32_t *out);

@@ -413,12 +413,14 @@ sys.path.insert(0, sys.argv[1])
 from densesurfelmapping_amd.replay import merge_clouds, shard_subsequences
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-a, b = shard_subsequences(11, world)[rank]
-n = (b - a) * 3 + (0 if rank else 2)          # ragged, rank-dependent cloud sizes
+N = int(sys.argv[2])
+a, b = shard_subsequences(N, world)[rank]
+n = (b - a) * 3 + (0 if rank else 2)          # ragged, rank-dependent cloud sizes (0 for an empty shard behind non-empty ones)
 cloud = (np.arange(n * 44, dtype=np.int64) * (rank + 1) % 251).astype(np.uint8)
 merged, counts = merge_clouds(torch.from_numpy(cloud))
 want = np.concatenate([(np.arange(c * 44, dtype=np.int64) * (r + 1) % 251).astype(np.uint8) for r, c in enumerate(counts)])
-assert counts == [((q - p) * 3 + (0 if r else 2)) for r, (p, q) in enumerate(shard_subsequences(11, world))], counts
+assert counts == [((q - p) * 3 + (0 if r else 2)) for r, (p, q) in enumerate(shard_subsequences(N, world))], counts
+assert N >= world or 0 in counts
 assert np.array_equal(merged.numpy(), want)
 empty, c0 = merge_clouds(torch.zeros(0, dtype=torch.uint8))
 assert empty.numel() == 0 and c0 == [0] * world
@@ -427,15 +429,30 @@ print("rank", rank, "ok")
 """
 
 
-def test_merge_clouds_gloo_world2(tmp_path):
+def _free_port():
+    """a TCP port the OS says is free right now (fixed ports collide when two runs share a host)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _torchrun(world, script, *args, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script), *[str(a) for a in args]],
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world,frames", [(2, 11), (8, 5)])
+def test_merge_clouds_gloo(tmp_path, world, frames):
+    """merge_clouds over gloo at world size 2 and at the target world size 8 -- there with fewer frames than ranks, so that
+    ranks with an empty cloud sit among ranks with surfels (and the all-empty case on every rank)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script), ROOT],
-                       env=env, capture_output=True, text=True, timeout=300)
+    r = _torchrun(world, script, ROOT, frames, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 _SHARD_WORKER = r"""
@@ -462,7 +479,7 @@ for t, img, dep, pose, ref in synth.sequence(src.cam, src.scene, b - a, start=a)
     assert ref == (t - a) // 5
     lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
 mine = np.load(os.path.join(out, f"shard_{rank}.npy"))
-assert len(lo) > 0 and mine.tobytes() == lo.tobytes(), (rank, len(mine), len(lo))
+assert (len(lo) > 0) == (b > a) and mine.tobytes() == lo.tobytes(), (rank, len(mine), len(lo))
 dist.barrier()
 if rank == 0:
     merged = np.load(os.path.join(out, "merged.npy"))
@@ -474,21 +491,20 @@ print("rank", rank, "ok")
 """
 
 
-def test_sharded_replay_gloo_world2(oracle_built, tmp_path):
+@pytest.mark.parametrize("world,frames", [(2, 23), (8, 6)])
+def test_sharded_replay_gloo(oracle_built, tmp_path, world, frames):
     """BASELINE configs[2] end to end on the CPU side: densesurfelmapping_amd.replay's driver (frame source ->
-    shard_subsequences -> one engine per rank -> merge_clouds) with two gloo ranks and the C restatement standing in for
+    shard_subsequences -> one engine per rank -> merge_clouds) with gloo ranks and the C restatement standing in for
     the HIP engine (injected here, the product has no such engine): rank r's map is the oracle's map of frames
     [a_r, b_r) fused from an empty map with keyframe indices restarting at 0, and the merged cloud is the concatenation
-    of the shards in rank order."""
+    of the shards in rank order.  World size 2, and the node's 8 with fewer frames than ranks: two
+    ranks replay nothing and contribute an empty cloud."""
     script = tmp_path / "worker.py"
     script.write_text(_SHARD_WORKER)
     out = tmp_path / "shards"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), ROOT, "23", str(out)],
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = _torchrun(world, script, ROOT, frames, out)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def test_replay_cli_refuses_without_gpus():

@@ -1034,6 +1034,36 @@ def test_sharded_replay_two_ranks_on_one_gpu(mods, tmp_path, source):
     assert head["merged_sha256"] == hashlib.sha256(merged.tobytes()).hexdigest()
 
 
+@pytest.mark.parametrize("depth,chunk", [(24, 16), (1, 5), (8, 24)])
+def test_replay_engine_streams_in_chunks(mods, depth, chunk):
+    """replay.HipEngine.replay -- what a rank of the sharded replay runs on its shard: frames streamed from page-locked
+    memory chunk by chunk (upload of chunk k+1 beside the kernels of chunk k, two slot halves in turn), through frame groups
+    -- over many chunks with a ragged last one, from a source whose frames are copied into the engine's page-locked blocks
+    by the prefetch thread and from one that keeps them page-locked itself; a second replay on the same engine continues
+    the sequence.  The map equals the oracle's for the same frames, byte for byte."""
+    api, synth, ob = mods
+    from densesurfelmapping_amd import replay
+    n, start = 131, 7
+    for prerender in (False, True):
+        src = replay.SyntheticSource(start + n, camera="TINY", seed=31, prerender=prerender)
+        eng = replay.HipEngine(src.cam, capacity=1 << 18, pipeline_depth=depth, chunk=chunk)
+        cut = start + 3 * chunk + 1
+        assert eng.replay(src, start, cut) == cut - start
+        orc, lo = ob.PortOracle(src.cam), np.zeros(0, ob.SURFEL_DTYPE)
+        for k, (img, dep, pose) in enumerate(src.frames(start, cut)):
+            lo, _ = orc.fuse_map(k // 5, img, dep, pose, lo)
+        assert eng.stats["zero_copy"] == prerender and eng.stats["frames"] == cut - start
+        assert not fields_equal(eng.cloud(), lo.astype(api.SURFEL_DTYPE)), (prerender, "first replay")
+        # ... and on: the same engine, keyframe indices restarting at 0 as replay() defines them
+        eng.replay(src, cut, start + n)
+        for k, (img, dep, pose) in enumerate(src.frames(cut, start + n)):
+            lo, _ = orc.fuse_map(k // 5, img, dep, pose, lo)
+        got = eng.cloud()
+        assert len(got) == len(lo) and not fields_equal(got, lo.astype(api.SURFEL_DTYPE)), (prerender, "second replay")
+        eng.close()
+        src.close()
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
     sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL).  Launched the way a

@@ -526,6 +526,41 @@ def test_fullhd_2m_fuse_and_warp(mods, gold):
     ff.close()
 
 
+def test_fullhd_frame_groups(mods, gold):
+    """BASELINE configs[4] as one sequence through one handle with frames in flight: ten 1920x1080 frames fused into the
+    2 M-surfel map of test_fullhd_2m_fuse_and_warp, strictly serial (pipeline depth 1) and through frame groups (depth 12:
+    the superpixel stages of four frames per batched launch, wave per seed; depth 24: eight frames, lane per seed), each
+    against the port oracle's replay byte for byte -- the first frame also against the reference-TU digest."""
+    api, synth, ob = mods
+    case = scale_cases.FULLHD_2M
+    row = gold["fullhd_2m"][0]
+    cam = getattr(synth, case["camera"])
+    scene = synth.Scene(**case["scene"])
+    n = 10
+    frames = list(synth.sequence(cam, scene, case["base_frames"] + n))[case["base_frames"]:]
+    big, first = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, case)
+    assert first[0] == frames[0][0]
+    start = scale_cases.large_map_variant(big, case["trials"][0], synth)
+    assert map_sha(start, ob.SURFEL_DTYPE) == row["in_sha256"]
+    oracle, m, models = ob.PortOracle(cam), start, []
+    for f in frames:
+        m, _ = oracle.fuse_map(f[4], f[1], f[2], f[3], m)
+        models.append(m)
+    assert map_sha(models[0], ob.SURFEL_DTYPE) == row["map_sha256"], "port oracle vs reference TU"
+    slots, refs, poses = api.FusionFunctions.pack_replay(list(range(n)), [f[4] for f in frames], [f[3] for f in frames])
+    for depth in (1, 12, 24):
+        ff = api.FusionFunctions.from_camera(cam, frame_slots=n, surfel_capacity=len(start) + 400_000, pipeline_depth=depth)
+        for i, f in enumerate(frames):
+            ff.frame_upload(i, f[1], f[2])
+        ff.map_upload(start.astype(api.SURFEL_DTYPE))
+        ff.replay_enqueue(slots, refs, poses)
+        got = ff.map_download()
+        assert len(got) == len(models[-1]) and len(got) > 2_000_000, (depth, len(got), len(models[-1]))
+        assert fields_equal(got, models[-1].astype(api.SURFEL_DTYPE)) == [], f"pipeline depth {depth}"
+        assert np.array_equal(ff.labels(), oracle.labels()), depth
+        ff.close()
+
+
 def test_node_at_kitti_resolution(mods):
     """The whole node on the GPU at the headline resolution (130 frames at 1226x370 through the message callbacks: stamp
     matching, pose graph, active / inactive sets in HBM, loop closure with the warp of ~50 k inactive surfels on ten
