@@ -37,18 +37,19 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, defines=(), out: str = LIB_PATH) -> str:
+    """The product library; `defines` / `out` build an instrumented copy beside it (tools/wave_stamps.py: DSM_WAVE_STAMPS=1)."""
+    if not force and not defines and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+           "-Wall", "-Wno-unused-function", "-Wno-unused-value"] + ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+    cmd += ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

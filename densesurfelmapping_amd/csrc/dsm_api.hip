@@ -943,7 +943,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         q.fit_small_cap = kFitSmallCap;
         CREATE_TRY(dev_alloc(h, &q.cur, 1));
         CREATE_TRY(dev_alloc(h, &q.rest_list, (size_t)((c.n_seed + 63) / 64) * kRestListCap * 64));
-        if (cfg->flags & DSM_FLAG_WAVE_STAMPS) CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));
+        if ((cfg->flags & DSM_FLAG_WAVE_STAMPS) && kWaveStamps) CREATE_TRY(dev_alloc(h, &q.stamps, (size_t)5 * c.n_seed * 8));
         q.params = h->d_params;
         if (np > 1) CREATE_TRY(hipEventRecord(pp.ev_map, h->stream)); // "buffers free"
     }
@@ -1674,6 +1674,7 @@ int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap) {
 // debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_FLAG_WAVE_STAMPS)
 int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
     if (!h || !out) return DSM_E_INVALID;
+    if (!kWaveStamps) return fail(h, DSM_E_STATE, "this library was built without phase stamps (-DDSM_WAVE_STAMPS=1: tools/wave_stamps.py builds such a copy)");
     if (!h->hc.stamps) return fail(h, DSM_E_STATE, "handle was created without DSM_FLAG_WAVE_STAMPS");
     int rc = bind_device(h);
     if (rc) return rc;

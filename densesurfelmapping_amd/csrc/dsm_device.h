@@ -8,6 +8,12 @@
 
 namespace dsm {
 
+// per-wave phase stamps of the per-seed kernels (dsm_debug_wave_stamps): compiled in only by -DDSM_WAVE_STAMPS=1
+#ifndef DSM_WAVE_STAMPS
+#define DSM_WAVE_STAMPS 0
+#endif
+constexpr bool kWaveStamps = DSM_WAVE_STAMPS != 0;
+
 constexpr int kIntMax = 0x7fffffff;
 typedef uint16_t label_t;             // a pixel's superpixel index in the label planes
 constexpr int kNoLabel = 0xffff;      // the reference's label -1 (pixels no cell reaches) in a label plane

@@ -81,9 +81,11 @@ __device__ __forceinline__ void wave_priority(int n) {
     else if (n > 64) __builtin_amdgcn_s_setprio(2);
 }
 
-// debug: record the shader clock of phase `ph` of seed s in per-seed kernel `kid` (lane 0 only)
+// debug: record the shader clock of phase `ph` of seed s in per-seed kernel `kid` (lane 0 only).  The shipped library is
+// built without them (kWaveStamps false: every call folds away, and dsm_create refuses DSM_FLAG_WAVE_STAMPS);
+// tools/wave_stamps.py builds its own instrumented copy with -DDSM_WAVE_STAMPS=1.
 __device__ __forceinline__ void stamp(const DeviceCtx *c, int kid, int s, int ph, int lane) {
-    if (c->stamps && lane == 0) c->stamps[((int64_t)kid * c->n_seed + s) * 8 + ph] = clock64();
+    if (kWaveStamps && c->stamps && lane == 0) c->stamps[((int64_t)kid * c->n_seed + s) * 8 + ph] = clock64();
 }
 
 // A block of the wave-per-seed kernels is 4 consecutive seeds; returns the seed of wave `wv`, or -1 outside the grid.

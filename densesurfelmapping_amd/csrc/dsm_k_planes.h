@@ -171,7 +171,7 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
     }
     if (m_fit == 0 && lane == 0) c->gn_hdr[s].m_in = 0;
     stamp(c, 3, s, 5, lane);
-    if (c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
+    if (kWaveStamps && c->stamps && lane == 0) c->stamps[((int64_t)3 * c->n_seed + s) * 8 + 7] = n;
 }
 
 // ---- seed statistics without a wave per seed
@@ -505,18 +505,9 @@ template <int TIER> struct FitShape {
 };
 
 // the group of seeds s0 .. s0+3 on one wave
-// FIRST_ONLY (k_seed_fit16): only the first Gauss-Newton step; the points stay in s_col, the damped inverse in s_solver, the
-// plane so far goes back in `first` -- or the group is queued for the full-length tier when a residual left the Huber core
-// (the steps that follow would have to sum the Hessian again) or a list is too long.
-struct FitFirst {
-    float4 plane; // this lane's seed (lane >> 4) after step 1
-    int m;        // its inlier count; 0: no fit
-    int s;        // the seed itself (-1: none)
-    bool ok;      // wave-uniform: steps 2-5 may reuse the inverse
-};
-template <int TIER, bool FIRST_ONLY = false> __device__ __forceinline__ void fit_group(const DeviceCtx *__restrict__ c, int s0,
+template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *__restrict__ c, int s0,
                                                              float (*s_col)[kFitCols][FitShape<TIER>::kStride], float *s_ones,
-                                                             double (*s_solver)[52], FitFirst *first = nullptr) {
+                                                             double (*s_solver)[52]) {
     constexpr int kChunks = FitShape<TIER>::kChunks;
     const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
     const int S = c->n_seed;
@@ -579,15 +570,8 @@ template <int TIER, bool FIRST_ONLY = false> __device__ __forceinline__ void fit
     int m_max = mg[0];
 #pragma unroll
     for (int q = 1; q < kFitSeeds; q++) m_max = mg[q] > m_max ? mg[q] : m_max;
-    if (FIRST_ONLY) {
-        first->plane = make_float4(hd.nx, hd.ny, hd.nz, 0.0f);
-        first->m = m;
-        first->s = live ? s : -1;
-        first->ok = false;
-    }
     if (TIER == kFitSmall && m_max > c->fit_small_cap) { // does not fit this tier's columns: queue it for the other
         if (lane == 0) c->worklist[atomicAdd(c->fit_big_count, 1)] = s0 / kFitSeeds;
-        if (FIRST_ONLY) first->m = 0;
         return;
     }
     const int m8 = (m_max + 7) & ~7;
@@ -655,7 +639,7 @@ template <int TIER, bool FIRST_ONLY = false> __device__ __forceinline__ void fit
             }
         stamp(c, 4, s0, 2, lane);
         unsigned long long h_masks[4] = {0, 0, 0, 0}; // class masks (this lane's seed) the cached inverse was built from
-        for (int it = 0; it < (FIRST_ONLY ? 1 : 5); it++) {
+        for (int it = 0; it < 5; it++) {
             if (it == 1) stamp(c, 4, s0, 3, lane);
             // residuals and Huber classes of every seed's list, lane-parallel; the class masks of a seed stay with its lanes
             unsigned long long noncore[4] = {0, 0, 0, 0};
@@ -739,22 +723,11 @@ template <int TIER, bool FIRST_ONLY = false> __device__ __forceinline__ void fit
             nz = (float)((double)nz - SU[2]);
             nb = (float)((double)nb - SU[3]);
             wave_lds_sync();
-            if (FIRST_ONLY) {
-                if (__ballot((noncore[0] | noncore[1] | noncore[2] | noncore[3]) != 0) != 0) { // from scratch, by the other tier
-                    if (lane == 0) c->worklist[atomicAdd(c->fit_big_count, 1)] = s0 / kFitSeeds;
-                    first->m = 0;
-                } else {
-                    first->plane = make_float4(nx, ny, nz, nb);
-                    first->ok = true;
-                }
-                return;
-            }
         }
     }
-    if (FIRST_ONLY) return; // (no seed of the group has a fit)
 
     stamp(c, 4, s0, 4, lane);
-    if (c->stamps && lane == 0) c->stamps[((int64_t)4 * c->n_seed + s0) * 8 + 7] = m_max;
+    if (kWaveStamps && c->stamps && lane == 0) c->stamps[((int64_t)4 * c->n_seed + s0) * 8 + 7] = m_max;
     // ---- the fitted plane goes to k_seed_finish (the seed record and the surfel it would create are a few hundred
     // double-typed instructions per seed: there a lane per seed, here they would run with 4 of 64 lanes)
     if (live && gl == 0 && m > 0) c->plane[s] = make_float4(nx, ny, nz, nb);
@@ -813,119 +786,6 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_finish(const
     c->spawn_ok[s] = ok ? 1 : 0;
     c->fused_flag[s] = 0;
     c->seed_weight[s] = depth_weight(out.mean_depth); // FF.cpp:274: what a surfel fusing into this seed weighs it with
-}
-
-// The plane fit with SIXTEEN seeds per workgroup of four waves (launches batched over many handles).  From the second
-// Gauss-Newton step on the damped inverse of the first is reused as long as every residual stays in the Huber core (on the
-// test data: nearly always; tests/hostemu.cpp counts), and only the four Jacobian sums of a seed are new -- in k_seed_fit
-// that is 16 of a wave's 64 lanes busy in an ordered sum that still runs the whole list, in three steps of five.  Here
-// the first step runs as there, four seeds per wave (fit_group<kFitSmall, FIRST_ONLY>), the points of all sixteen seeds stay
-// in LDS, and steps 2-5 run for the sixteen on ONE wave: lane = 4 * seed + a carries J(a) -- a quarter of the ordered-sum
-// instructions of those steps, and every one of them costs an issue slot (float -> double conversions at a quarter of the
-// fp32 rate).  A quad of seeds whose lists are too long, or that meets a residual outside the core at any step, is queued
-// for the full-length tier of k_seed_fit (kFitLarge), which fits it from scratch: same arithmetic on every path.
-// (Round 3 measured this form with launches of 8 handles, alone on the GPU: 41 % fewer instructions and 13 % slower -- the
-// tail of a workgroup is one wave.  With 32 handles per launch and four batches sharing the machine the stage is bound by the
-// instructions issued, not by a wave's latency: profiles/r05_*.)
-constexpr int kFit16 = 16;
-#ifndef DSM_FIT16
-#define DSM_FIT16 1
-#endif
-constexpr bool kUseFit16 = DSM_FIT16 != 0; // (build switch of the round's A/B: tools/_exp/ab)
-template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_fit16(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
-    const BlockOf blk = block_of<BATCH>();
-    DeviceCtx batch_ctx;
-    if (BATCH) batch_ctx = load_ctx(batch + blk.z);
-    const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    __shared__ __attribute__((aligned(16))) float s_col[kFit16][kFitCols][kFitSmallStride];
-    __shared__ __attribute__((aligned(16))) float s_ones[4][8];
-    __shared__ double s_solver[kFit16][52];
-    __shared__ __attribute__((aligned(16))) float s_plane[kFit16][4];
-    __shared__ int s_m[kFit16], s_seed[kFit16];
-    __shared__ unsigned s_live[kFit16 / kFitSeeds];
-    const int lane = lane_id();
-    const int quad = threadIdx.x >> 6; // phase I: one wave per four seeds, as in k_seed_fit
-    const int S = c->n_seed;
-    const int n16 = (S + kFit16 - 1) / kFit16;
-    const int s0 = (n16 - 1 - blk.x) * kFit16; // bottom rows (long lists) first, see seed_of_block
-    {
-        // every column zero up to its end: the sums of steps 2-5 run to the longest of the sixteen lists
-        float4 *z = reinterpret_cast<float4 *>(&s_col[quad * kFitSeeds][0][0]);
-        for (int v = lane; v < kFitSeeds * kFitCols * kFitSmallStride / 4; v += 64) z[v] = make_float4(0, 0, 0, 0);
-        wave_lds_sync();
-        FitFirst f;
-        f.plane = make_float4(0, 0, 0, 0);
-        f.m = 0;
-        f.s = -1;
-        f.ok = false;
-        if (s0 + quad * kFitSeeds < S) fit_group<kFitSmall, true>(c, s0 + quad * kFitSeeds, s_col + quad * kFitSeeds, s_ones[quad], s_solver + quad * kFitSeeds, &f);
-        if ((lane & (kFitLanes - 1)) == 0) {
-            const int q = quad * kFitSeeds + (lane >> 4);
-            *reinterpret_cast<float4 *>(s_plane[q]) = f.plane;
-            s_m[q] = f.ok ? f.m : 0;
-            s_seed[q] = f.s;
-        }
-        if (lane == 0) s_live[quad] = f.ok ? 1u : 0u;
-    }
-    __syncthreads();
-    if (quad != 0) return; // phase II: the sixteen seeds on one wave
-    unsigned live_quads = s_live[0] | s_live[1] << 1 | s_live[2] << 2 | s_live[3] << 3; // quads whose steps 2-5 run here
-    live_quads = __builtin_amdgcn_readfirstlane(live_quads);
-    if (live_quads == 0) return;
-    const float hr_above = flt_above(c->huber); // the Huber class tests in fp32 (dsm_math.h)
-    int m_max = 0;
-#pragma unroll
-    for (int q = 0; q < kFit16; q++) m_max = s_m[q] > m_max ? s_m[q] : m_max;
-    m_max = __builtin_amdgcn_readfirstlane(m_max);
-    const int m8 = (m_max + 7) & ~7;
-    const int sq = lane >> 2, a = lane & 3; // this lane: J(a) of seed sq
-    const int mq = ((live_quads >> (sq >> 2)) & 1u) ? s_m[sq] : 0;
-    if (lane < 8) s_ones[0][lane] = 1.0f; // (quad 0 may have had nothing to fit)
-    wave_lds_sync();
-    const float *xc = s_col[sq][3], *yc = a == 3 ? s_ones[0] : s_col[sq][a];
-    const double *SO = s_solver[sq] + 28;
-    double *SJ = s_solver[sq] + 44;
-    for (int it = 1; it < 5; it++) {
-        // residuals of the sixteen lists at once, a seed's four lanes taking four elements each in turn; a residual
-        // outside the core retires the seed's quad of seeds (the padding's residual stays +0.0)
-        {
-            const float4 pl = *reinterpret_cast<const float4 *>(s_plane[sq]);
-            bool out_of_core = false;
-            for (int i = a * 4; i < m8; i += 16) {
-                const float4 p0 = *reinterpret_cast<const float4 *>(&s_col[sq][0][i]), p1 = *reinterpret_cast<const float4 *>(&s_col[sq][1][i]),
-                             p2 = *reinterpret_cast<const float4 *>(&s_col[sq][2][i]);
-                float4 r;
-                r.x = p0.x * pl.x + p1.x * pl.y + p2.x * pl.z + pl.w;
-                r.y = p0.y * pl.x + p1.y * pl.y + p2.y * pl.z + pl.w;
-                r.z = p0.z * pl.x + p1.z * pl.y + p2.z * pl.z + pl.w;
-                r.w = p0.w * pl.x + p1.w * pl.y + p2.w * pl.z + pl.w;
-                const bool v0 = i < mq, v1 = i + 1 < mq, v2 = i + 2 < mq, v3 = i + 3 < mq;
-                out_of_core = out_of_core || (v0 && !(fabsf(r.x) < hr_above)) || (v1 && !(fabsf(r.y) < hr_above)) ||
-                              (v2 && !(fabsf(r.z) < hr_above)) || (v3 && !(fabsf(r.w) < hr_above));
-                r.x = v0 ? r.x : 0.0f; r.y = v1 ? r.y : 0.0f; r.z = v2 ? r.z : 0.0f; r.w = v3 ? r.w : 0.0f;
-                *reinterpret_cast<float4 *>(&s_col[sq][3][i]) = r;
-            }
-            const unsigned long long bad = __ballot(out_of_core);
-#pragma unroll
-            for (int quad4 = 0; quad4 < kFit16 / kFitSeeds; quad4++) {
-                if (((bad >> (16 * quad4)) & 0xffffull) != 0 && ((live_quads >> quad4) & 1u)) {
-                    live_quads &= ~(1u << quad4);
-                    if (lane == 0) c->worklist[atomicAdd(c->fit_big_count, 1)] = s0 / kFitSeeds + quad4;
-                }
-            }
-        }
-        if (live_quads == 0) return;
-        wave_lds_sync();
-        // J(a) of sixteen seeds at once: ordered double sums over the padded lists, halved and doubled as in k_seed_fit
-        const double acc = fit_ordered_sum_core(xc, yc, 1, a == 3 ? 0 : 1, m8);
-        SJ[a] = acc;
-        wave_lds_sync();
-        const double u = ((SO[a] * SJ[0] + SO[4 + a] * SJ[1]) + SO[8 + a] * SJ[2]) + SO[12 + a] * SJ[3]; // FF.cpp:176-180
-        s_plane[sq][a] = (float)((double)s_plane[sq][a] - u);
-        wave_lds_sync();
-    }
-    const int seed = s_seed[sq];
-    if (a == 0 && seed >= 0 && s_m[sq] > 0 && ((live_quads >> (sq / kFitSeeds)) & 1u)) c->plane[seed] = *reinterpret_cast<const float4 *>(s_plane[sq]);
 }
 
 template <bool BATCH, int TIER> __global__ __launch_bounds__(64) void k_seed_fit(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {

@@ -440,7 +440,7 @@ __device__ __forceinline__ void update_seed_finish(const DeviceCtx *__restrict__
         if (!mean_depth_is_settled(md)) md = huber_passes_wave(dl, lt, nd, md, 0, c->huber, lane);
     }
     stamp(c, sweep, s, 5, lane);
-    if (c->stamps && lane == 0) c->stamps[((int64_t)sweep * c->n_seed + s) * 8 + 7] = nd;
+    if (kWaveStamps && c->stamps && lane == 0) c->stamps[((int64_t)sweep * c->n_seed + s) * 8 + 7] = nd;
     if (lane == 0) {
         c->core_stage[s] = make_float4(mx, my, mi, md);
         c->stable_stage[s] = stable;

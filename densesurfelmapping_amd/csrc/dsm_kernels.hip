@@ -117,8 +117,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
         hipLaunchStage(k_seed_points<false>, k_seed_points<true>, g_seed_wave, dim3(256));
     }
     DSM_MARK();
-    if (lanes && kUseFit16) hipLaunchStage(k_seed_fit16<true>, k_seed_fit16<true>, dim3((S + kFit16 - 1) / kFit16), dim3(256));
-    else hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitSmall>), dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
+    hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitSmall>), dim3((S + kFitSeeds - 1) / kFitSeeds), dim3(64));
     if (batched) hipLaunchStage((k_seed_fit<false, kFitAll>), (k_seed_fit<true, kFitLarge>), dim3(kFitLargeBlocks), dim3(64));
     hipLaunchStage(k_seed_finish<false>, k_seed_finish<true>, g_seed_thr, dim3(256));
     DSM_MARK();

@@ -106,7 +106,9 @@ typedef struct dsm_config {
                                      Handles of a batch cannot have it; replays that stream their frames -- batched or
                                      not -- use dsm_frames_upload_async, which needs no flag and no stream per handle. */
 
-#define DSM_FLAG_WAVE_STAMPS 4u /* debug: allocate the per-wave phase-stamp buffer read by dsm_debug_wave_stamps */
+#define DSM_FLAG_WAVE_STAMPS 4u /* debug: allocate the per-wave phase-stamp buffer read by dsm_debug_wave_stamps -- in a library
+                                   built with -DDSM_WAVE_STAMPS=1 (tools/wave_stamps.py); the shipped build has no stamp code in
+                                   its kernels, ignores the flag, and dsm_debug_wave_stamps reports DSM_E_STATE */
 
 typedef struct dsm_handle dsm_handle;
 

@@ -5,7 +5,14 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the shipped library holds no stamp code: this tool runs on its own instrumented copy (built here if missing)
+STAMPED = os.path.join(ROOT, "tools", "_exp", "ab", "libdsm_hip_stamps.so")
+if not os.path.exists(STAMPED):
+    from densesurfelmapping_amd import build  # noqa: E402
+    build.build_library(force=True, defines=("DSM_WAVE_STAMPS=1",), out=STAMPED)
+os.environ["DSM_LIB_PATH"] = STAMPED
 from densesurfelmapping_amd import api, synth  # noqa: E402
 
 cam, scene = synth.KITTI_1226, synth.Scene()
