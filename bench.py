@@ -73,7 +73,7 @@ BATCHED_KERNELS_OF_STAGE = {
     "seed_points": ["k_pixel_normals<true>", "k_seed_stats<true>"],
     "seed_fit": ["k_seed_fit<true, 1>", "k_seed_fit<true, 2>", "k_seed_finish<true>"],
 }
-PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r04_pmc_traffic.json", "r04_pmc_traffic_batched.json", "r04_pmc_sq_batch8.md"
+PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r05_pmc_traffic.json", "r05_pmc_traffic_batched.json", "r05_pmc_sq_batch8.md"
 DEFAULT_SUBSEQUENCES = 128  # batched mode: 4 batches of 32 (round 4; 32 in 4 batches of 8 until then)
 
 
@@ -99,7 +99,7 @@ def pmc_traffic(kernels, name, per_launch=None):
 
 def valu_issue(fps_per_gpu, clock_ghz=None):
     """The roof that binds the batched superpixel stages: VALU instruction issue.  Wave-instructions per frame from the
-    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r04_pmc_sq_batch8.md;
+    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r05_pmc_sq_batch8.md;
     the counts are per launch, a frame launches the sweep kernels two or three times) against what 1 024 SIMDs issue at one
     wave64 instruction per 4 cycles.  clock_ghz: the shader clock sampled during the timed region (2.4 GHz assumed when it
     could not be read).  None when no pass is on file."""
@@ -690,8 +690,8 @@ def main():
                                "frames_timed": int(nfb), "mean_live_surfels": round(mtb), "mean_new_surfels": round(kb, 1),
                                "timing": "HIP events between the kernels of an eager replay of ONE batch alone on the GPU, the empty-interval "
                                          "overhead (event_overhead_us) subtracted; `rocprofv3 --kernel-trace` of the same launches: "
-                                         "profiles/r04_kernel_trace_batch32x1.md; in the timed region four batches share the machine and a "
-                                         "launch takes longer (profiles/r04_kernel_trace_batch32x4_default.md)",
+                                         "profiles/r05_kernel_trace_batch32x1.md; in the timed region four batches share the machine and a "
+                                         "launch takes longer (profiles/r05_kernel_trace_batch32x4_default.md)",
                                "note": "the timed region launches every kernel once per batch of subsequences; roofline_single_launch is the "
                                        "same kernel launched for one subsequence"}
             # the WHOLE frame's algorithmic bytes over the whole frame's kernel time (the launch set

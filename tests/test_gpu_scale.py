@@ -527,16 +527,17 @@ def test_fullhd_2m_fuse_and_warp(mods, gold):
 
 
 def test_fullhd_frame_groups(mods, gold):
-    """BASELINE configs[4] as one sequence through one handle with frames in flight: ten 1920x1080 frames fused into the
+    """BASELINE configs[4] as one sequence through one handle with frames in flight: fourteen 1920x1080 frames fused into the
     2 M-surfel map of test_fullhd_2m_fuse_and_warp, strictly serial (pipeline depth 1) and through frame groups (depth 12:
-    the superpixel stages of four frames per batched launch, wave per seed; depth 24: eight frames, lane per seed), each
+    the superpixel stages of four frames per batched launch, wave per seed, a ragged end of two frame by frame; depth 24: eight
+    frames, lane per seed, a ragged end of six), each
     against the port oracle's replay byte for byte -- the first frame also against the reference-TU digest."""
     api, synth, ob = mods
     case = scale_cases.FULLHD_2M
     row = gold["fullhd_2m"][0]
     cam = getattr(synth, case["camera"])
     scene = synth.Scene(**case["scene"])
-    n = 10
+    n = 14
     frames = list(synth.sequence(cam, scene, case["base_frames"] + n))[case["base_frames"]:]
     big, first = scale_cases.large_map_inputs(ob.PortOracle(cam), synth, ob.SURFEL_DTYPE, case)
     assert first[0] == frames[0][0]
