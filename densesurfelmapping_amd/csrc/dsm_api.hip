@@ -37,7 +37,7 @@ constexpr int kBatchStreams = 4;
 hipError_t batch_streams_reserve(int device); // see BatchStreamPool
 hipStream_t batch_stream_at(int device, int i);
 constexpr int kUploadStreams = 2;
-hipStream_t device_upload_stream(int device, int *which); // asynchronous frame uploads of the handles on the device (dsm_frame_upload_async)
+hipStream_t device_upload_stream(int device, int *which, bool high_priority); // asynchronous frame uploads of the handles on the device (dsm_frame_upload_async)
 constexpr uint64_t kBatchBit = 1ull << 62;    // UpEntry::pending: a batch stream has not waited for this upload of the handle yet
 
 } // namespace
@@ -191,6 +191,22 @@ struct dsm_handle {
     int up_n = 0;
     // the frame slots the frames being submitted read (set by the enqueue calls that know them; everything otherwise)
     int read_lo = 0, read_hi = INT32_MAX;
+    // ... and the other direction: which enqueue calls still READ which slots.  rd_ring = the last kRdRing calls of
+    // dsm_replay_enqueue, oldest first: ev = everything the call enqueued has finished (recorded on the map stream behind it:
+    // it covers the calls before it), [lo, hi) = the slots its frames read.  An asynchronous upload waits for the newest
+    // entry that reads a slot it overwrites -- not for everything enqueued so far: with three groups of slots in turn
+    // (replay.py) the upload of chunk k + 1 waits for chunk k - 2, which finished long ago, so the wait never stalls the
+    // hardware queue the upload stream shares with the handle's pipeline streams.  reads_untracked: frames were enqueued
+    // some other way (frame by frame, through a batch, timed / debug / drop-in calls): the next upload waits for the whole
+    // map stream once (ev_fence), which covers them -- and, the upload stream being in order, every later upload too.
+    struct RdEntry {
+        hipEvent_t ev = nullptr;
+        int lo = 0, hi = 0;
+    };
+    static constexpr int kRdRing = 4;
+    RdEntry rd_ring[kRdRing];
+    int rd_n = 0;
+    bool reads_untracked = true;
     int up_which = -1; // which of the device's upload streams this handle's uploads take (dealt out at its first upload)
     int64_t frames_submitted = 0, frames_done = 0;
     int batches_joined = 0; // dsm_batch_create copied this handle's context: it must not change any more
@@ -414,6 +430,7 @@ int capture(dsm_handle *h, const DeviceCtx &ctx, bool with_compaction, int lo, i
 // frame's pipeline stream, fuse + tail on the map stream
 int submit_frame(dsm_handle *h, bool with_compaction) {
     h->shadow_n = -1;
+    h->reads_untracked = true; // (dsm_replay_enqueue, which lists what it reads, puts the flag back)
     if (int rc = map_grows(h, 1)) return rc;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
@@ -482,6 +499,7 @@ bool group_path(const dsm_handle *h) {
 }
 int submit_group(dsm_handle *h) {
     h->shadow_n = -1;
+    h->reads_untracked = true;
     const int G = group_size(h);
     if (int rc = map_grows(h, G)) return rc;
     const int p0 = (int)(h->frames_submitted % h->n_pipe); // a multiple of G
@@ -542,6 +560,7 @@ int submit_group(dsm_handle *h) {
 // run some or all stages of the next frame serially on the map stream (timed replays, state-level taps)
 int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, int hi) {
     h->shadow_n = -1;
+    h->reads_untracked = true;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
     if (h->n_pipe > 1 && (h->params_pending & kSerialBit)) {
@@ -570,6 +589,7 @@ int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, i
 // ---- drop-in calls: everything on the map stream, in two parts, so that the host can look at the caller's surfel
 // array while the superpixel stages (which need the frame only) already run
 int submit_part(dsm_handle *h, bool with_compaction, bool map_part) {
+    h->reads_untracked = true;
     if (int rc = map_grows(h, 1)) return rc;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
@@ -1005,6 +1025,8 @@ void dsm_destroy(dsm_handle *h) {
         if (i == h->up_n - 1) (void)hipEventSynchronize(h->up_ring[i].ev);
         (void)hipEventDestroy(h->up_ring[i].ev);
     }
+    for (int i = 0; i < dsm_handle::kRdRing; i++)
+        if (h->rd_ring[i].ev) (void)hipEventDestroy(h->rd_ring[i].ev);
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
@@ -1409,12 +1431,25 @@ int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *imag
     if (n > 1 && (img_frame_step < img_step * (size_t)hh || depth_frame_step < depth_step * (size_t)hh)) return fail(h, DSM_E_INVALID, "frame step smaller than a frame");
     int rc = bind_device(h);
     if (rc) return rc;
-    hipStream_t up = device_upload_stream(h->device, &h->up_which);
+    hipStream_t up = device_upload_stream(h->device, &h->up_which, h->batches_joined > 0); // (decided at the handle's first upload)
     if (!up) return fail(h, DSM_E_HIP, "no upload stream on device %d", h->device);
-    // behind every frame enqueued so far for this handle (its map stream runs fuse + tail of every frame after the
-    // superpixel stages that read the slots, and waits for the batches the handle takes part in): they may read these slots
-    HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
-    HIP_TRY(h, hipStreamWaitEvent(up, h->ev_fence, 0));
+    // behind the frames that may still read these slots (dsm_handle::rd_ring): the newest dsm_replay_enqueue call that
+    // reads one of them -- or, if frames were enqueued some other way since the last upload, behind everything enqueued so
+    // far for this handle (its map stream runs fuse + tail of every frame after the superpixel stages that read the slots,
+    // and waits for the batches the handle takes part in)
+    if (h->reads_untracked) {
+        HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(up, h->ev_fence, 0));
+        h->reads_untracked = false;
+        h->rd_n = 0; // (covered by the fence; the events stay in their places for reuse)
+    } else {
+        for (int i = h->rd_n - 1; i >= 0; i--) {
+            const dsm_handle::RdEntry &e = h->rd_ring[i];
+            if (e.lo >= slot0 + n || slot0 >= e.hi) continue;
+            HIP_TRY(h, hipStreamWaitEvent(up, e.ev, 0));
+            break;
+        }
+    }
     uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot0 * h->hc.slot_elems;
     float *dd = (float *)h->hc.depth_base + (int64_t)slot0 * h->hc.slot_elems;
     const size_t plane = (size_t)pitch * (size_t)hh; // elements of one slot
@@ -1510,6 +1545,7 @@ int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const
     int r_lo, r_hi;
     slot_range(slots, n, &r_lo, &r_hi);
     const ReadSlots reads(h, r_lo, r_hi);
+    const bool untracked_before = h->reads_untracked;
     for (int i = 0; i < n;) {
         int m = 0;
         if ((rc = stage_params_batch(h, n - i, slots + i, ref_idx + i, poses16 + 16 * (size_t)i,
@@ -1526,7 +1562,28 @@ int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const
         }
         i += m;
     }
-    if (n) h->fence_pending = true;
+    if (n) {
+        h->fence_pending = true;
+        // what this call reads, for the uploads that follow (dsm_handle::rd_ring); the oldest entry folds into the one after it
+        hipEvent_t ev = nullptr;
+        if (h->rd_n == dsm_handle::kRdRing) {
+            const dsm_handle::RdEntry old = h->rd_ring[0];
+            for (int i = 1; i < h->rd_n; i++) h->rd_ring[i - 1] = h->rd_ring[i];
+            h->rd_n--;
+            dsm_handle::RdEntry &nx = h->rd_ring[0];
+            nx.lo = old.lo < nx.lo ? old.lo : nx.lo;
+            nx.hi = old.hi > nx.hi ? old.hi : nx.hi;
+            ev = old.ev;
+        }
+        if (!ev) ev = h->rd_ring[h->rd_n].ev; // (left behind by an earlier reset)
+        if (!ev) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        dsm_handle::RdEntry &e = h->rd_ring[h->rd_n++];
+        e.ev = ev;
+        e.lo = r_lo;
+        e.hi = r_hi;
+        HIP_TRY(h, hipEventRecord(e.ev, h->stream));
+        h->reads_untracked = untracked_before;
+    }
     return DSM_OK;
 }
 
@@ -1698,8 +1755,8 @@ struct BatchStreamPool {
     hipStream_t st[64][kBatchStreams] = {};
     bool made[64] = {};
     int next[64] = {};
-    hipStream_t up[64][kUploadStreams] = {}; // asynchronous frame uploads, created at the first dsm_frame_upload_async on the device
-    int up_next[64] = {};
+    hipStream_t up[64][2 * kUploadStreams] = {}; // asynchronous frame uploads, created at the first dsm_frame_upload_async on the device: [0, kUploadStreams) at normal priority, the rest at the highest
+    int up_next[64][2] = {};
 } g_batch_streams;
 
 // (The reserved streams live as long as the process, like the HIP context they belong to: a static destructor would run
@@ -1724,16 +1781,30 @@ hipStream_t batch_stream_at(int device, int i) {
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
     return g_batch_streams.made[device] ? g_batch_streams.st[device][i] : nullptr;
 }
-// TWO upload streams per device, shared by its handles (a stream per handle would spread the handles' own streams
-// unevenly over the hardware queues, see DSM_FLAG_UPLOAD_STREAM in dsm.h): the copies are DMA transfers ordered by
+// TWO upload streams per device and priority, shared by its handles (a stream per handle would spread the handles' own
+// streams unevenly over the hardware queues, see DSM_FLAG_UPLOAD_STREAM in dsm.h): the copies are DMA transfers ordered by
 // events, they need no queue of their own per subsequence -- but one stream's transfers run one after the other on one
-// DMA engine (36.7 GB/s of 1226x370 frames on this box); two keep two engines busy.  which < 0: deal the next one out.
-hipStream_t device_upload_stream(int device, int *which) {
+// DMA engine (36.7 GB/s of 1226x370 frames on one box); two keep two engines busy.  *which < 0: deal the next one out.
+// high_priority (the handles of batches): streams at the highest stream priority.  The runtime keeps a pool of hardware
+// queues per priority, so these do not share a hardware queue with any kernel-launching stream of the process -- a copy that
+// waits for its slots to be free is a barrier packet, and a barrier packet holds up whatever else is multiplexed onto its
+// queue.  Four batches streaming their frames: 21.5-21.7 k frames/s against 15.0-15.4 k with normal-priority upload streams
+// on the same box (51 of the 47-57 GB/s the link delivers alone; three alternating rounds, profiles/r05_streaming.md).  One
+// handle streaming alone is the other way round (11.5 k against 12.9 k): it keeps the normal-priority streams.
+hipStream_t device_upload_stream(int device, int *which, bool high_priority) {
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
-    if (*which < 0) *which = g_batch_streams.up_next[device]++ % kUploadStreams;
+    if (*which < 0) *which = (high_priority ? kUploadStreams : 0) + g_batch_streams.up_next[device][high_priority ? 1 : 0]++ % kUploadStreams;
     hipStream_t &st = g_batch_streams.up[device][*which];
-    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    if (!st) {
+        int least = 0, greatest = 0;
+        hipError_t e = hipSuccess;
+        if (*which >= kUploadStreams && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest);
+        else
+            e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) st = nullptr;
+    }
     return st;
 }
 hipStream_t batch_stream_take(int device) {
@@ -1831,6 +1902,7 @@ int batch_advance(dsm_batch *b, int m) {
     for (dsm_handle *h : b->hs) {
         BHIP_TRY(b, hipStreamWaitEvent(h->stream, b->ev_out, 0));
         h->shadow_n = -1;
+        h->reads_untracked = true;
         h->frames_submitted += m;
         const int64_t up = (int64_t)h->map_upper + (int64_t)m * h->hc.n_seed;
         h->map_upper = up > h->hc.cap ? h->hc.cap : (int)up;

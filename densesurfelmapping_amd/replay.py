@@ -160,16 +160,21 @@ class HipEngine:
     sequence: frame groups (pipeline depth 24: the superpixel stages of eight consecutive frames per batched launch, fuse
     + compaction in frame order on the map stream) and frames streamed from page-locked host memory in chunks --
     dsm_frames_upload_async for chunk k+1, then dsm_replay_enqueue for chunk k, so that the transfer of one chunk runs
-    beside the kernels of the one before (two halves of 2 x chunk frame slots).  Frames reach the page-locked blocks on a
+    beside the kernels of the one before.  THREE groups of `chunk` frame slots take turns: the upload of chunk k+1 overwrites
+    the slots of chunk k-2, which finished long ago -- the library orders an upload behind the newest enqueue call that
+    reads its slots (include/dsm.h), and a wait that is already satisfied does not stall the hardware queue the upload
+    stream shares with the handle's pipeline streams (with two groups it waits for chunk k-1: 11 k instead of 15 k frames/s).  Frames reach the page-locked blocks on a
     prefetch thread (decode / render / copy) unless the source already keeps them there (`pinned_run`).  `fuse` is the
     frame-at-a-time form of the same thing (SurfelMap::fuse_map, surfel_map.cpp:1060-1113).  There is no other engine in this package:
     without a gfx950 device the constructor raises (DSM_E_NO_DEVICE)."""
+
+    GROUPS = 3  # groups of frame slots used in turn
 
     def __init__(self, cam, device=0, capacity=0, pipeline_depth=24, chunk=48):
         from . import api
         self._api = api
         self.chunk = max(1, int(chunk))
-        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=2 * self.chunk, surfel_capacity=capacity,
+        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=self.GROUPS * self.chunk, surfel_capacity=capacity,
                                                   pipeline_depth=pipeline_depth)
         self.ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
         self.n = 0
@@ -177,7 +182,7 @@ class HipEngine:
         self.stats = {}
 
     def fuse(self, image, depth, pose, ref_idx):  # one frame: blocking upload into a slot, one enqueue
-        slot = self.n % (2 * self.chunk)
+        slot = self.n % (self.GROUPS * self.chunk)
         self.ff.frame_upload(slot, image, depth)
         self.ff.fuse_frame_resident(slot, ref_idx, pose)
         self.n += 1
@@ -212,7 +217,7 @@ class HipEngine:
             except BaseException as e:  # noqa: BLE001 -- handed to the consumer
                 ready.put((None, None, e))
 
-        def send(k, half):  # chunk k -> slot half `half`
+        def send(k, half):  # chunk k -> slot group `half`
             t0, n = chunks[k]
             if zero_copy:
                 i = 0
@@ -247,8 +252,8 @@ class HipEngine:
             for k, (t0, n) in enumerate(chunks):
                 if k + 1 < len(chunks):
                     take(k + 1)
-                    send(k + 1, (k + 1) & 1)  # BEFORE chunk k is enqueued: ordered behind chunk k - 1, whose slots it overwrites
-                half = k & 1
+                    send(k + 1, (k + 1) % self.GROUPS)  # BEFORE chunk k is enqueued; ordered behind chunk k - 2, whose slots it overwrites
+                half = k % self.GROUPS
                 slots = [half * C + i for i in range(n)]
                 refs = [(t0 - a + i) // keyframe_every for i in range(n)]
                 ff.replay_enqueue(*ff.pack_replay(slots, refs, np.stack(poses_of.pop(k))))

@@ -1064,24 +1064,26 @@ def test_replay_engine_streams_in_chunks(mods, depth, chunk):
         src.close()
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks
-    sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL).  Launched the way a
-    user would: `python bench.py --gpus 2` starts its own ranks."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_on_one_gpu(world):
+    """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks, and with the
+    node's eight, sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL).  Launched
+    the way a user would: `python bench.py --gpus N` starts its own ranks."""
     import subprocess
     import sys
     env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--streams", "2", "--frames-per-step", "4"],
-                       env=env, capture_output=True, text=True, timeout=600)
+                        "--gpus", str(world), "--steps", "20" if world == 2 else "6", "--warmup", "5" if world == 2 else "2", "--streams", "2",
+                        "--frames-per-step", "4"],
+                       env=env, capture_output=True, text=True, timeout=900)
     out = _bench_line(r)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["final_surfels_all_ranks"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N=1 only
     mg = out["multi_gpu"]
-    assert mg["world_size_seen_by_backend"] == 2 and len(mg["per_rank_frames_per_s"]) == 2
+    assert mg["world_size_seen_by_backend"] == world and len(mg["per_rank_frames_per_s"]) == world
     assert mg["min_rank_frames_per_s"] <= mg["max_rank_frames_per_s"] and mg["final_cloud_all_gather_ms"] > 0
     # value is the whole job over the slowest rank's time: never more than the sum of the ranks' own rates
     assert out["value"] <= sum(mg["per_rank_frames_per_s"]) * 1.001
