@@ -15,6 +15,13 @@ if os.path.join(ROOT, "tests") not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # no test may hang a run: a stuck stream wait is a failure after 15 minutes (the longest test takes one), not a wait for
+    # the driver's own limit.  pytest-timeout's thread method: a signal would not interrupt a call that is stuck inside the
+    # HIP runtime.  (Only if the plugin is installed and nobody chose a timeout on the command line.)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900
+        if not getattr(config.option, "timeout_method", None):
+            config.option.timeout_method = "thread"
 
 
 def _run(cmd, **kw):
