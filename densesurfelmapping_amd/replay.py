@@ -163,7 +163,7 @@ class HipEngine:
     beside the kernels of the one before.  THREE groups of `chunk` frame slots take turns: the upload of chunk k+1 overwrites
     the slots of chunk k-2, which finished long ago -- the library orders an upload behind the newest enqueue call that
     reads its slots (include/dsm.h), and a wait that is already satisfied does not stall the hardware queue the upload
-    stream shares with the handle's pipeline streams (with two groups it waits for chunk k-1: 11 k instead of 15 k frames/s).  Frames reach the page-locked blocks on a
+    stream shares with the handle's pipeline streams (with two groups it waits for chunk k-1: 11 k instead of 13-14 k frames/s).  Frames reach the page-locked blocks on a
     prefetch thread (decode / render / copy) unless the source already keeps them there (`pinned_run`).  `fuse` is the
     frame-at-a-time form of the same thing (SurfelMap::fuse_map, surfel_map.cpp:1060-1113).  There is no other engine in this package:
     without a gfx950 device the constructor raises (DSM_E_NO_DEVICE)."""

@@ -229,7 +229,7 @@ int dsm_frame_upload_device(dsm_handle *h, int slot, const void *image_dev, size
  * So a replay buffers in chunks: upload chunk k+1, THEN enqueue chunk k -- chunk k waits for upload k only, and upload k+1
  * runs beside its kernels.  With two groups of slots upload k+1 waits for chunk k-1, whose slots it overwrites; with three
  * in turn it waits for chunk k-2, which finished long ago, and never holds up the hardware queue it shares with the handle's
- * own streams (densesurfelmapping_amd/replay.py: 15 k instead of 11 k frames/s for one sequence at 1226x370).  The source must be page-locked (dsm_host_alloc) and stay untouched until
+ * own streams (densesurfelmapping_amd/replay.py: 13-14 k instead of 11 k frames/s for one sequence at 1226x370).  The source must be page-locked (dsm_host_alloc) and stay untouched until
  * dsm_frame_uploads_wait (or dsm_synchronize after a frame that reads the slot).  Rows laid out with the slot pitch
  * (dsm_frame_pitch elements per row: img_step = pitch, depth_step = 4 * pitch; the pad columns are never read) go up
  * as one transfer per plane, any other step row by row. ---- */
