@@ -115,6 +115,16 @@ def frame_paths(seq_dir: str, i: int):
     return os.path.join(seq_dir, "image_0", "%06d.png" % i), os.path.join(seq_dir, "depth_0", "%06d.npy" % i)
 
 
+def load_frame(seq_dir: str, i: int, bf: float = BF_SEQ_00_02):
+    """frame i as kitti_publisher hands it over: (grey uint8 [H,W], depth float32 [H,W] = bf / disparity, +inf where the
+    disparity is 0 -- publisher.py:35-40).  A module-level function, so that decode workers (fresh interpreters) can run it."""
+    img_path, dep_path = frame_paths(seq_dir, i)
+    image = read_grey(img_path)
+    with np.errstate(divide="ignore"):
+        depth = (bf / np.load(dep_path)).astype(np.float32)
+    return image, depth
+
+
 def camera_from_calib(seq_dir: str, width: int, height: int, far=30.0, near=0.5) -> synth.Camera:
     """Intrinsics from the sequence's calib.txt (P0: fx 0 cx 0 0 fy cy 0 ...), else KITTI04-12.yaml:8-11's values."""
     calib = os.path.join(seq_dir, "calib.txt")

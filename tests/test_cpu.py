@@ -845,6 +845,17 @@ def test_kitti_layout_reader(synth, tmp_path):
     back = list(back)
     assert (cam2.width, cam2.height, dfp) == (cam.width, cam.height, 10) and len(back) == len(ev)
     assert np.array_equal(back[4][2], ev[4][2]) and np.array_equal(back[5][3], ev[5][3])
+    # the replay driver's frame source over the same directory: serial, and decoded by worker processes -- same frames, in order
+    from densesurfelmapping_amd import replay
+    serial = replay.KittiSource(str(seq), str(tmp_path / "poses.txt"))
+    pooled = replay.KittiSource(str(seq), str(tmp_path / "poses.txt"), decode_workers=2)
+    assert serial.n_frames == pooled.n_frames == n
+    fa, fb = list(serial.frames(1, n)), list(pooled.frames(1, n))
+    pooled.close()
+    assert len(fa) == len(fb) == n - 1
+    for (ia, da, pa), (ib, db, pb), t in zip(fa, fb, range(1, n)):
+        assert np.array_equal(ia, frames[t][0]) and np.array_equal(ia, ib) and np.array_equal(da, db) and np.array_equal(pa, pb)
+        assert (da[frames[t][1] == 0] == 0).all()  # (this directory stores depth 0 as an infinite disparity; bf / inf = 0)
 
 
 # ------------------------------------------------------------------ the reference's own sources on top of the product
