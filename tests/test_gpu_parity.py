@@ -1034,6 +1034,49 @@ def test_sharded_replay_two_ranks_on_one_gpu(mods, tmp_path, source):
     assert head["merged_sha256"] == hashlib.sha256(merged.tobytes()).hexdigest()
 
 
+@pytest.mark.parametrize("depth", [1, 4])
+def test_async_uploads_between_frame_by_frame_and_chunked_enqueues(mods, depth):
+    """The two orderings of dsm_frame(s)_upload_async on one handle, mixed: frames enqueued one at a time
+    (dsm_fuse_frame_resident: the library does not list what they read, so the next upload waits for everything enqueued so
+    far) and in chunks (dsm_replay_enqueue: an upload waits for the newest call that reads its slots), slots reused at once,
+    no host wait anywhere -- a frame must never see the upload that follows it, nor miss the one before it.  Against the
+    oracle, byte for byte."""
+    api, synth, ob = mods
+    cam, scene = synth.TINY, synth.Scene(seed=77)
+    n = 40
+    frames = list(synth.sequence(cam, scene, n))
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=4, surfel_capacity=1 << 17, pipeline_depth=depth)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    pin = api.PinnedFrames(ff, n)
+    for t, img, dep, pose, ref in frames:
+        pin.set(t, img, dep)
+    t = 0
+    while t < n:
+        if (t // 8) % 2 == 0:  # one frame at a time through two slots in turn
+            for _ in range(min(8, n - t)):
+                ff.frame_upload_async(t & 1, pin.image(t), pin.depth(t))
+                ff.fuse_frame_resident(t & 1, frames[t][4], frames[t][3])
+                t += 1
+        else:  # chunks of four through all four slots, the next chunk sent before this one is enqueued would need eight: here
+            # every chunk overwrites the slots of the one before it -- the upload must wait for that one's frames
+            for _ in range(2):
+                m = min(4, n - t)
+                if m <= 0:
+                    break
+                ff.frames_upload_async(0, pin, t, m)
+                ff.replay_enqueue(*ff.pack_replay(list(range(m)), [f[4] for f in frames[t:t + m]], [f[3] for f in frames[t:t + m]]))
+                t += m
+    got = ff.map_download()
+    ff.frame_uploads_wait()
+    orc, lo = ob.PortOracle(cam), np.zeros(0, ob.SURFEL_DTYPE)
+    for _, img, dep, pose, ref in frames:
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+    assert len(got) == len(lo) and not fields_equal(got, lo.astype(api.SURFEL_DTYPE))
+    assert np.array_equal(ff.labels(), orc.labels())
+    pin.close()
+    ff.close()
+
+
 @pytest.mark.parametrize("depth,chunk", [(24, 16), (1, 5), (8, 24)])
 def test_replay_engine_streams_in_chunks(mods, depth, chunk):
     """replay.HipEngine.replay -- what a rank of the sharded replay runs on its shard: frames streamed from page-locked
