@@ -208,6 +208,11 @@ struct dsm_handle {
     int rd_n = 0;
     bool reads_untracked = true;
     int up_which = -1; // which of the device's upload streams this handle's uploads take (dealt out at its first upload)
+    bool touched = true; // a per-handle call may have put work on the handle's stream since a batch last ordered itself behind it
+    // the other way round: the handle's stream has to come behind the batch it last advanced with (its frames read and
+    // write the handle's buffers) -- the wait is put onto the stream when the stream is next used (bind_device), not after
+    // every enqueue call of the batch: a wait is a barrier packet on a hardware queue that other batches' graphs share
+    hipEvent_t batch_order_ev = nullptr;
     int64_t frames_submitted = 0, frames_done = 0;
     int batches_joined = 0; // dsm_batch_create copied this handle's context: it must not change any more
     int map_upper = 0; // host-side upper bound of the resident map size
@@ -258,14 +263,23 @@ template <typename T> hipError_t dev_alloc(dsm_handle *h, T **out, size_t count)
     return hipMemsetAsync(p, 0, count * sizeof(T) + 256, h->stream);
 }
 
+int order_behind_batch(dsm_handle *h) {
+    if (h->batch_order_ev) {
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->batch_order_ev, 0));
+        h->batch_order_ev = nullptr;
+    }
+    return DSM_OK;
+}
 int bind_device(dsm_handle *h) {
     HIP_TRY(h, hipSetDevice(h->device));
-    return DSM_OK;
+    h->touched = true; // (every per-handle entry point comes through here; the batch calls do not: see batch_stage)
+    return order_behind_batch(h);
 }
 
 // make room in the parameter rings for n more frames
 int reserve_params(dsm_handle *h, int n) {
     if (h->frames_submitted + n - h->frames_done > kParamRing) {
+        if (int rc = order_behind_batch(h)) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->frames_done = h->frames_submitted;
     }
@@ -298,7 +312,8 @@ int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16, cons
 
 // stage the params of up to n consecutive frames with one host-to-device copy; returns how many
 // were staged (limited by the ring's wrap-around point)
-int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t *ref_idx, const float *poses16, const float *inv_poses16, int *staged) {
+int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t *ref_idx, const float *poses16, const float *inv_poses16, int *staged,
+                       hipStream_t batch_stream = nullptr) {
     const int ring = (int)(h->frames_submitted % kParamRing);
     int m = n < kParamRing - ring ? n : kParamRing - ring;
     if (m > kParamRing / 2) m = kParamRing / 2;
@@ -315,7 +330,8 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
         fp.pad[0] = fp.pad[1] = 0;
     }
     if (h->n_pipe == 1) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+        // (a batch copies them on ITS stream, in order with the kernels that read them: see batch_stage)
+        HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, batch_stream ? batch_stream : h->stream));
     } else {
         HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(h, hipEventRecord(h->ev_params, h->copy_stream));
@@ -1057,6 +1073,7 @@ int dsm_seed_count(const dsm_handle *h) { return h ? h->hc.n_seed : DSM_E_INVALI
 
 int dsm_stream(dsm_handle *h, void **hip_stream) {
     if (!h || !hip_stream) return DSM_E_INVALID;
+    if (int rc = bind_device(h)) return rc; // (the caller is about to use the stream: it comes behind the handle's batch first)
     *hip_stream = (void *)h->stream;
     return DSM_OK;
 }
@@ -1860,19 +1877,37 @@ int batch_rings_in_step(dsm_batch *b) {
     return DSM_OK;
 }
 
-// params of frames [i0, i0+m) of every handle go up on the handles' own streams; the batch stream waits for them
+// params of frames [i0, i0+m) of every handle go up on the BATCH stream, in order with the kernels that read them.  (Until
+// round 5 they went up on the handles' own streams, with an event per handle for the batch stream to wait for: 32 copies and
+// 32 markers per enqueue call on streams that HIP multiplexes onto the same four hardware queues the OTHER batches' graphs
+// are queued on -- a batch's next chunk could not start before whatever another batch had queued in front of those markers
+// had run.)  The batch stream is ordered behind a handle's own stream only when a per-handle call may have put work there
+// since the last time (dsm_handle::touched: uploads, a replay of its own, a map download ...).
+#ifndef DSM_BATCH_PARAMS_ON_BATCH
+#define DSM_BATCH_PARAMS_ON_BATCH 1
+#endif
 int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
                 const float *inv_poses16 = nullptr) {
     for (size_t j = 0; j < b->hs.size(); j++) {
         dsm_handle *h = b->hs[j];
         if (!h->map_valid) return bfail(b, DSM_E_STATE, "handle %zu has no resident map: call dsm_map_upload first (n may be 0)", j);
         const size_t o = j * (size_t)n_frames + (size_t)i0;
+        if (!DSM_BATCH_PARAMS_ON_BATCH || h->touched) {
+            BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
+            BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
+            h->touched = false;
+        }
+        // (a handle that last advanced with ANOTHER batch, and whose own stream has not been used since: behind that batch)
+        if (h->batch_order_ev && h->batch_order_ev != b->ev_out) BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->batch_order_ev, 0));
         int staged = 0;
-        const int rc = stage_params_batch(h, m, slots + o, ref_idx + o, poses16 + 16 * o, inv_poses16 ? inv_poses16 + 16 * o : nullptr, &staged);
+        const int rc = stage_params_batch(h, m, slots + o, ref_idx + o, poses16 + 16 * o, inv_poses16 ? inv_poses16 + 16 * o : nullptr, &staged,
+                                          DSM_BATCH_PARAMS_ON_BATCH ? b->stream : nullptr);
         if (rc) return bfail(b, rc, "handle %zu: %s", j, h->err.c_str());
         if (staged != m) return bfail(b, DSM_E_STATE, "handle %zu: parameter rings of the batch are out of step", j);
-        BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
-        BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
+        if (!DSM_BATCH_PARAMS_ON_BATCH) {
+            BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
+            BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
+        }
         if (h->up_n) { // frames this handle was sent with dsm_frame(s)_upload_async: the uploads that wrote the slots these frames read
             int r_lo, r_hi;
             slot_range(slots + o, m, &r_lo, &r_hi);
@@ -1900,7 +1935,8 @@ int batch_map_grows(dsm_batch *b, int m) {
 int batch_advance(dsm_batch *b, int m) {
     BHIP_TRY(b, hipEventRecord(b->ev_out, b->stream));
     for (dsm_handle *h : b->hs) {
-        BHIP_TRY(b, hipStreamWaitEvent(h->stream, b->ev_out, 0));
+        if (DSM_BATCH_PARAMS_ON_BATCH) h->batch_order_ev = b->ev_out; // (waited for when the handle's stream is next used)
+        else BHIP_TRY(b, hipStreamWaitEvent(h->stream, b->ev_out, 0));
         h->shadow_n = -1;
         h->reads_untracked = true;
         h->frames_submitted += m;
@@ -1970,13 +2006,16 @@ int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
 
 void dsm_batch_destroy(dsm_batch *b) {
     if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
     { // the batch's copy of the handles' contexts goes with it (a handle destroyed before its batch is simply skipped)
         std::lock_guard<std::mutex> lk(g_live_mu);
         for (dsm_handle *h : b->hs)
-            if (g_live.count(h) && h->batches_joined > 0) h->batches_joined--;
+            if (g_live.count(h)) {
+                if (h->batches_joined > 0) h->batches_joined--;
+                if (h->batch_order_ev == b->ev_out) h->batch_order_ev = nullptr; // (the batch has finished: nothing left to wait for)
+            }
     }
-    (void)hipSetDevice(b->device);
-    if (b->stream) (void)hipStreamSynchronize(b->stream);
     if (b->graph) (void)hipGraphExecDestroy(b->graph);
     if (b->ev_out) (void)hipEventDestroy(b->ev_out);
     if (b->have_events)
@@ -2022,7 +2061,8 @@ int dsm_batch_synchronize(dsm_batch *b) {
     if (!b) return DSM_E_INVALID;
     BHIP_TRY(b, hipSetDevice(b->device));
     for (size_t j = 0; j < b->hs.size(); j++) {
-        const int rc = sync_and_fetch_counts(b->hs[j]);
+        int rc = order_behind_batch(b->hs[j]); // (the handles' streams come behind the batch when they are next used: now)
+        if (!rc) rc = sync_and_fetch_counts(b->hs[j]);
         if (rc) return bfail(b, rc, "handle %zu: %s", j, b->hs[j]->err.c_str());
     }
     return DSM_OK;
