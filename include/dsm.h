@@ -257,15 +257,18 @@ int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const
 int dsm_synchronize(dsm_handle *h);
 /* number of new surfels created by the last completed frame; synchronises */
 int dsm_last_new_count(dsm_handle *h, int32_t *n_new);
-/* the handle's hipStream_t, for event timing by the caller */
+/* the handle's hipStream_t, for event timing by the caller.  (A handle that advances with a batch: its stream is put behind
+ * the batch's work at the handle's next dsm_* call -- this one included -- not after every batch call; fetch the stream after
+ * the batch calls whose results the caller's own work on it should come behind.) */
 int dsm_stream(dsm_handle *h, void **hip_stream);
 
 /* ---- batches: handles of equal image size on one device, each with its own map and frames (independent subsequences,
  * surfel_map.cpp has no counterpart: it fuses one frame at a time), advancing in LOCKSTEP: every kernel of a frame is
  * launched once for the whole batch (grid z = handle).  Launch overheads, cold caches and the slowest waves of a kernel
  * are shared by all subsequences instead of paid by each: this is what bench.py's headline replays.  Handles must have
- * pipeline_depth 1 and a resident map; they stay usable on their own between batch calls (every handle's stream is
- * ordered behind the batch). ---- */
+ * pipeline_depth 1 and a resident map; they stay usable on their own between batch calls (a handle's stream is ordered
+ * behind the batch when it is next used, by every per-handle call and by dsm_batch_synchronize; a batch call itself touches
+ * no stream but the batch's own -- the handles' streams share hardware queues with the other batches). ---- */
 typedef struct dsm_batch dsm_batch;
 int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out);
 void dsm_batch_destroy(dsm_batch *b);
