@@ -1014,6 +1014,7 @@ void dsm_destroy(dsm_handle *h) {
         g_live.erase(h);
     }
     (void)hipSetDevice(h->device);
+    if (h->stream && h->batch_order_ev) (void)hipStreamWaitEvent(h->stream, h->batch_order_ev, 0); // (a batch may still be working on this handle's buffers)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 4; i++) {
         if (h->g_group[i]) (void)hipGraphExecDestroy(h->g_group[i]);
