@@ -519,6 +519,32 @@ int emu_fuse_fp32_mismatches(const float *z, const float *a, const float *b, int
     }
     return bad;
 }
+// the robust mean depth with the settled-mean shortcut (dsm_math.h: a +inf member needs no pass) against the reference's loop
+// as written (FF.cpp:530-556, no shortcut), on lists that hold +inf members, overflowing sums and ordinary depths
+int emu_settled_mean_mismatches(const float *lists, const int *len, int n_lists, int stride, double huber) {
+    int bad = 0;
+    for (int i = 0; i < n_lists; i++) {
+        const float *d = lists + (size_t)i * stride;
+        const int n = len[i];
+        float sum = 0;
+        for (int k = 0; k < n; k++) sum += d[k];
+        float mean_depth = sum / n;
+        for (int it = 0; it < 5; it++) { // the reference, statement by statement
+            float sum_a = 0, sum_b = 0;
+            for (int k = 0; k < n; k++) {
+                float residual = mean_depth - d[k];
+                if (residual < huber && residual > -huber) { sum_a += 2 * residual; sum_b += 2; }
+                else sum_a += residual > 0 ? huber : -1 * huber;
+            }
+            float delta_depth = -sum_a / (sum_b + 10.0);
+            mean_depth = mean_depth + delta_depth;
+            if (delta_depth < 0.01 && delta_depth > -0.01) break;
+        }
+        const float got = huber_mean_depth(d, n, sum, huber);
+        bad += memcmp(&mean_depth, &got, 4) != 0 && !(mean_depth != mean_depth && got != got);
+    }
+    return bad;
+}
 // table-driven inverse (the form the HIP kernel evaluates lane-parallel) vs the closed form
 void emu_inverse4d(const double *a, double *closed, double *tabled) { inverse4<double>(a, closed); inverse4_tabled<double>(a, tabled); }
 

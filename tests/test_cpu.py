@@ -405,6 +405,31 @@ def test_bench_reads_the_committed_profiles():
         assert leg in rec, leg
 
 
+def test_settled_mean_depth_shortcut(hostemu_lib):
+    """dsm_math.h, mean_depth_is_settled: a superpixel with a +inf member depth (the reference's feed has them wherever the
+    disparity is 0) keeps the +inf mean it starts from through every Huber-Newton pass, so the kernels skip the passes.
+    huber_mean_depth WITH the shortcut against the reference's loop written out, on 20 000 lists: ordinary depths, one or
+    many +inf members anywhere in the list, sums that overflow to +inf, single-element lists."""
+    import ctypes as C
+    lib = C.CDLL(hostemu_lib)
+    lib.emu_settled_mean_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
+    rng = np.random.default_rng(7)
+    n_lists, stride = 20000, 64
+    lists = (rng.uniform(0.11, 80.0, size=(n_lists, stride))).astype(np.float32)
+    lens = rng.integers(1, stride + 1, size=n_lists).astype(np.int32)
+    kind = rng.integers(0, 4, size=n_lists)
+    for i in np.nonzero(kind == 1)[0]:  # one +inf member
+        lists[i, rng.integers(0, lens[i])] = np.inf
+    for i in np.nonzero(kind == 2)[0]:  # many
+        lists[i, :lens[i]][rng.random(lens[i]) < 0.4] = np.inf
+    for i in np.nonzero(kind == 3)[0][:2000]:  # finite members whose sum overflows
+        lists[i, :lens[i]] = np.float32(3.0e38)
+    n_inf_lists = int(sum(np.isinf(lists[i, :lens[i]]).any() or kind[i] == 3 for i in range(n_lists)))
+    assert n_inf_lists > 5000
+    for huber in (0.4, 0.05):
+        assert lib.emu_settled_mean_mismatches(lists.ctypes.data, lens.ctypes.data, n_lists, stride, huber) == 0
+
+
 def test_shard_subsequences():
     from densesurfelmapping_amd.replay import shard_subsequences
     sh = shard_subsequences(4541, 8)
