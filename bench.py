@@ -371,7 +371,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed form against the CPU oracle")
     ap.add_argument("--legs", default=os.environ.get("DSM_BENCH_LEGS", "all"),
                     help="comma-separated legs beside the headline to run (single_sequence, dropin, fullhd, live, node, kitti_like, "
-                         "streamed, sharded_replay, bounded_map); default all")
+                         "streamed, sharded_replay, bounded_map, tum_like); default all")
     ap.add_argument("--oracle-replay-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -414,9 +414,19 @@ def main():
     n_scene_k = min(B, 4)
     scenes_k = [synth.Scene(seed=12345 + 1000 * rank + 17 * b, frames_per_period=period, stereo=True, saturate_above=150.0, intensity_levels=8)
                 for b in range(n_scene_k)]
+    # BASELINE configs[3]'s kind of input (the `tum_like` leg): 640x480 under the RGB-D constant set, a hand-held loop through a
+    # room, depth as a Kinect + the TUM dataset's uint16 / 5000 PNGs deliver it; and the same room through an ideal sensor
+    period_t = 100
+    scenes_t = [synth.Scene(seed=7 + 1000 * rank + 17 * b, tum=True, frames_per_period=period_t, intensity_noise=8.0, checker=25.0, n_boxes=6)
+                for b in range(n_scene_k)]
+    scenes_ts = [synth.Scene(**dict(synth.dataclasses.asdict(sc_), tum_sensor=False)) for sc_ in scenes_t]
+    tum_on = extras and ("all" in legs or "tum_like" in legs)
     if extras:
         jobs += [(cam_v, scene_v, i) for i in range(30)] + [(cam_h, scene_h, i) for i in range(10)]
         jobs += [(cam, scenes_k[b], i) for b in range(n_scene_k) for i in range(period)]
+    n_before_t = len(jobs)
+    if tum_on:
+        jobs += [(cam_v, sc_, i) for sc_ in scenes_t + scenes_ts for i in range(period_t)]
     workers = max(1, min(48, (os.cpu_count() or 2) // (2 * max(world, 1))))
     t_r = time.perf_counter()
     frames_all = synth.render_many(jobs, workers)
@@ -425,6 +435,7 @@ def main():
     frames_v = frames_all[n_scene * period:n_scene * period + 30] if extras else []
     frames_h = frames_all[n_scene * period + 30:n_scene * period + 40] if extras else []
     rendered_k = [frames_all[n_scene * period + 40 + b * period:n_scene * period + 40 + (b + 1) * period] for b in range(n_scene_k)] if extras else []
+    rendered_t = [frames_all[n_before_t + b * period_t:n_before_t + (b + 1) * period_t] for b in range(2 * n_scene_k)] if tum_on else []
 
     # The checker of the timed region, started now so that it runs beside everything below: the CPU oracle replays one
     # subsequence per batch from its empty map through the LAST timed frame (a single-threaded replay of (W + K) * F frames
@@ -1139,7 +1150,7 @@ def main():
             h_.close()
         open_picks = None
         try:
-            open_picks = json.load(open(os.path.join(ROOT, "profiles", "r05_open_picks.json")))
+            open_picks = json.load(open(os.path.join(ROOT, "profiles", "r06_open_picks.json")))
         except (OSError, ValueError):
             pass
         out["kitti_like"] = {"value": round(fps_k, 1), "unit": "frames/s", "fraction_of_headline": round(fps_k / (fps / world), 3),
@@ -1154,6 +1165,97 @@ def main():
                                       "(kitti_publisher/scripts/publisher.py:37-40); image quantised to 8 grey levels, 255 above 150",
                              "note": f"the headline's form ({n_bat} batches of {nb} in flight) on {n_scene_k} stereo scenes; parity of this input "
                                      "family: tests/test_gpu_scale.py [stereo_inf, stereo_zero] against reference-TU vectors"}
+
+    if tum_on and args.mode == "batched":
+        # BASELINE configs[3] through the timed form: the headline's batched replay -- 128 subsequences, four
+        # batches of 32 in flight -- at 640x480 under the RGB-D constant set (fusion_functions.h:17-21) on TUM-style frames
+        # (Kinect-quantised uint16 / 5000 depth: a hundred-odd distinct values per frame; zero in the projector's shadows,
+        # in blobs, beyond 0.4-5 m and at the border; a hand-held closed loop, a keyframe every 4 frames), beside the SAME
+        # room and trajectory through an ideal sensor; then the live callback (host frame in, one graph replay, wait) on
+        # the same frames.
+        n_seed_v = (cam_v.width // 8) * (cam_v.height // 8)
+
+        def family(rendered_f, scenes_f, label):
+            def mk(b):
+                ff = api.FusionFunctions.from_camera(cam_v, device=device, frame_slots=period_t, surfel_capacity=1 << 20, pipeline_depth=1)
+                for i, (img, dep) in enumerate(rendered_f[b % n_scene_k]):
+                    ff.frame_upload(i, img, dep)
+                ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+                return ff
+
+            def plan_f(b, n):
+                ph = (b // n_scene_k) * 13 % period_t
+                return api.FusionFunctions.pack_replay([(t + ph) % period_t for t in range(n)], [t // 4 for t in range(n)],
+                                                       np.stack([scenes_f[b % n_scene_k].pose(t + ph) for t in range(n)]))
+            k_f, w_f = min(K, 10), 3
+            n_f = (w_f + k_f) * F
+            hs = [mk(b) for b in range(B)]
+            pl = [plan_f(b, n_f) for b in range(B)]
+            bts = [api.Batch([hs[b] for b in grp]) for grp in groups_b]
+
+            def run_f(lo, hi):
+                def one(g):
+                    for c0 in range(lo, hi, 64):
+                        c1 = min(hi, c0 + 64)
+                        sb, rb, pb, nn = api.Batch.pack([(pl[b][0][c0:c1], pl[b][1][c0:c1], pl[b][2][c0:c1]) for b in groups_b[g]])
+                        bts[g].replay_enqueue(sb, rb, pb, nn)
+                list(pool.map(one, range(n_bat)))
+                for bt_ in bts:
+                    bt_.synchronize()
+            run_f(0, w_f * F)
+            t_f = time.perf_counter()
+            run_f(w_f * F, n_f)
+            dt_f = time.perf_counter() - t_f
+            tiers = [hs[b].debug_tier_counts() for b in range(0, B, max(1, B // 8))]  # the last frame of eight of the subsequences
+            sizes_f = [h_.map_size() for h_ in hs]
+            for bt_ in bts:
+                bt_.close()
+            nb = len(groups_b[0])
+            bt = api.Batch(hs[:nb])
+            sb, rb, pb, nn = api.Batch.pack([(pl[b][0][:24], pl[b][1][:24], pl[b][2][:24]) for b in range(nb)])
+            st_f, _ = bt.replay_timed(sb, rb, pb, nn)
+            ov_f = bt.event_overhead_ms * 1e3
+            per_f = {k: max(v[0] / max(v[1], 1) * 1e3 - ov_f, 0.0) for k, v in st_f.items()}
+            bt.close()
+            for h_ in hs:
+                h_.close()
+            mean = lambda key, i=None: round(float(np.mean([(t_[key] if i is None else t_[key][i]) for t_ in tiers])), 1)  # noqa: E731
+            return {"value": round(B * k_f * F / dt_f, 1), "unit": "frames/s", "subsequences": B, "steps": k_f, "input": label,
+                    "mean_live_surfels": round(float(np.mean(sizes_f))),
+                    "batched_kernel_us": {k: round(v, 2) for k, v in per_f.items()},
+                    "batched_frame_kernel_sum_us_per_frame": round(sum(per_f.values()) / nb, 1),
+                    "second_tier_seeds_per_frame": {"of_seeds": n_seed_v,
+                                                    "huber_rest_by_sweep": [mean("huber_rest_by_sweep", i) for i in range(3)],
+                                                    "long_list_by_sweep": [mean("long_list_by_sweep", i) for i in range(3)],
+                                                    "fit_long_groups_of_4": mean("fit_long_groups")}}
+        res_t = family(rendered_t[:n_scene_k], scenes_t, "Kinect-quantised uint16 / 5000 depth, shadows, blobs, 0.4-5 m")
+        res_s = family(rendered_t[n_scene_k:], scenes_ts, "the same room and trajectory through an ideal sensor (float depth, 2 % holes)")
+        # the live callback on the TUM frames: pageable host frame in, one graph replay, wait (30 Hz budget: 33 ms)
+        ff = api.FusionFunctions.from_camera(cam_v, device=device, frame_slots=2, surfel_capacity=1 << 20)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        lat = []
+        for t in range(300):
+            img_v, dep_v = rendered_t[0][t % period_t]
+            t_l = time.perf_counter()
+            ff.frame_upload(t & 1, img_v, dep_v)
+            ff.fuse_frame_resident(t & 1, t // 4, scenes_t[0].pose(t))
+            ff.synchronize()
+            if t >= 50:
+                lat.append(time.perf_counter() - t_l)
+        lat = np.array(lat) * 1e3
+        live_map = ff.map_size()
+        ff.close()
+        open_picks = None
+        try:
+            open_picks = json.load(open(os.path.join(ROOT, "profiles", "r06_open_picks.json")))["families"].get("tum_like (640x480, RGB-D constants)")
+        except (OSError, ValueError, KeyError):
+            pass
+        out["tum_like"] = dict(res_t, ratio_to_ideal_sensor=round(res_t["value"] / res_s["value"], 3), ideal_sensor=res_s,
+                               live_callback={"latency_ms_p50": round(float(np.median(lat)), 3), "latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
+                                              "frames": int(len(lat)), "map_surfels": live_map},
+                               open_picks=open_picks,
+                               note=f"BASELINE configs[3]'s input family in the headline's form ({n_bat} batches of {len(groups_b[0])} in flight, 640x480, RGB-D "
+                                    "constants, keyframe every 4); parity: tests/test_gpu_scale.py [tum_room, tum_sparse] against reference-TU vectors")
 
     if leg_on("bounded_map") and args.mode == "batched":
         # The headline replay never lets a keyframe leave the window, so its maps grow without bound and 83 % of B_alg is

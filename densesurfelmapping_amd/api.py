@@ -54,7 +54,7 @@ ABI_SYMBOLS = (
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
     "dsm_batch_replay_timed",
-    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps", "dsm_debug_set_fit_small_cap",
+    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps", "dsm_debug_set_fit_small_cap", "dsm_debug_tier_counts",
     "dsm_debug_run_stages", "dsm_debug_get_label_buffer", "dsm_debug_set_label_buffer", "dsm_debug_get_seed_state",
     "dsm_debug_set_seed_state",
 )
@@ -145,6 +145,7 @@ def load_library():
     lib.dsm_seed_count.argtypes = [_vp]
     lib.dsm_debug_wave_stamps.argtypes = [_vp, _vp]
     lib.dsm_debug_set_fit_small_cap.argtypes = [_vp, C.c_int32]
+    lib.dsm_debug_tier_counts.argtypes = [_vp, _vp]
     lib.dsm_debug_run_stages.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]
     lib.dsm_debug_get_label_buffer.argtypes = [_vp, C.c_int, _vp]
     lib.dsm_debug_set_label_buffer.argtypes = [_vp, C.c_int, _vp]
@@ -480,6 +481,13 @@ class FusionFunctions:
         core = np.ascontiguousarray(core, np.float32)
         stable = np.ascontiguousarray(stable, np.int32)
         self._check(self._lib.dsm_debug_set_seed_state(self._h, _ptr(core), _ptr(stable)))
+
+    def debug_tier_counts(self):
+        """second-tier occupancy of the latest frame's lane-per-seed kernels (include/dsm.h, dsm_debug_tier_counts)"""
+        out = np.zeros(8, np.int32)
+        self._check(self._lib.dsm_debug_tier_counts(self._h, out.ctypes.data_as(_vp)))
+        return {"huber_rest_by_sweep": [int(out[0]), int(out[2]), int(out[4])], "long_list_by_sweep": [int(out[1]), int(out[3]), int(out[5])],
+                "fit_long_groups": int(out[6])}
 
     def debug_set_fit_small_cap(self, cap):
         self._check(self._lib.dsm_debug_set_fit_small_cap(self._h, int(cap)))

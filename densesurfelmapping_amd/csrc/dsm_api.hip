@@ -1746,6 +1746,18 @@ int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap) {
     return DSM_OK;
 }
 
+// debug tap: how many seeds the latest frame's lane-per-seed kernels handed on to their second tiers
+int dsm_debug_tier_counts(dsm_handle *h, int32_t *out /* 8 */) {
+    if (!h || !out) return DSM_E_INVALID;
+    int rc = bind_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->hc.rest_count, 6 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out + 6, h->hc.fit_big_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    out[7] = 0;
+    return DSM_OK;
+}
+
 // debug tap: per-wave phase stamps of the per-seed kernels (only with DSM_FLAG_WAVE_STAMPS)
 int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out /* 5 * n_seed * 8 */) {
     if (!h || !out) return DSM_E_INVALID;

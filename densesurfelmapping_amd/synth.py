@@ -86,6 +86,20 @@ class Scene:
     zero_disparity_inf: bool = True  # False: an unmatched pixel is depth 0 (a publisher that masks them)
     saturate_above: float = 0.0      # > 0: every grey value above it reads 255
     intensity_levels: int = 0        # > 0: the grey values below saturation quantised to this many levels
+    # ---- a TUM-RGBD-style feed (BASELINE configs[3]; ORB_SLAM2/Examples/ROS/ORB_SLAM2/src/ros_rgbd.cc feeds the node from a
+    # Kinect): a hand-held camera in a closed room, depth as the sensor + the dataset's 16-bit PNGs deliver it -- quantised
+    # in disparity (1/8 pixel of a 7.5 cm x 580 px projector baseline), stored as uint16 = metres x 5000, ZERO outside
+    # 0.4-5 m, in the projector's occlusion shadows beside every foreground edge, in blobs the sensor lost and in a
+    # band at the right border.  The trajectory is a closed loop: pose(t) == pose(t mod frames_per_period).
+    tum: bool = False
+    tum_depth_scale: float = 5000.0
+    tum_near: float = 0.4
+    tum_far: float = 5.0
+    kinect_bf: float = 43.5          # baseline x focal of the depth sensor, metre x pixel
+    kinect_subpixel: float = 0.125
+    blob_fraction: float = 0.012     # fraction of 5x7-pixel blocks the sensor returns nothing for
+    tum_border: int = 8              # columns at the right border without depth (registration to the colour image)
+    tum_sensor: bool = True          # False: same room and trajectory through an ideal sensor (float depth + noise, 2 % holes): the bench's comparison run
 
     @property
     def period(self) -> float:
@@ -114,6 +128,8 @@ class Scene:
 
     def pose(self, t: int) -> np.ndarray:
         """cam->world 4x4 float32 for frame ``t`` (any non-negative integer)."""
+        if self.tum:
+            return _tum_pose(self, t)
         ph = 2.0 * np.pi * (t % self.frames_per_period) / self.frames_per_period
         yaw = np.deg2rad(self.yaw_amp_deg) * np.sin(ph)
         c, s = np.cos(yaw), np.sin(yaw)
@@ -124,8 +140,118 @@ class Scene:
         return m.astype(np.float32)
 
 
+def _rot(axis: int, a: float) -> np.ndarray:
+    c, s = np.cos(a), np.sin(a)
+    m = np.eye(3)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    m[i, i], m[i, j], m[j, i], m[j, j] = c, -s, s, c
+    return m
+
+
+def _tum_pose(scene: Scene, t: int) -> np.ndarray:
+    """Hand-held sweep through a room, closed after `frames_per_period` frames: a +-40 degree pan with a nodding pitch, a
+    little roll, a 0.3 m wander of the camera centre and a tremor (hash of the frame index) on all six."""
+    P = scene.frames_per_period
+    tl = t % P
+    ph = 2.0 * np.pi * tl / P
+    j = (_uniform01(np.arange(6, dtype=np.uint32) + np.uint32(6 * tl), scene.seed * 977 + 5) - 0.5) * 2.0
+    yaw = np.deg2rad(40.0) * np.sin(ph) + np.deg2rad(0.15) * j[0]
+    pitch = np.deg2rad(6.0) + np.deg2rad(8.0) * np.sin(2.0 * ph + 0.7) + np.deg2rad(0.15) * j[1]
+    roll = np.deg2rad(3.0) * np.sin(3.0 * ph + 0.3) + np.deg2rad(0.15) * j[2]
+    m = np.eye(4, dtype=np.float64)
+    m[:3, :3] = _rot(1, yaw) @ _rot(0, pitch) @ _rot(2, roll)
+    m[:3, 3] = (0.30 * np.sin(ph + 0.4) + 0.003 * j[3], 0.06 * np.sin(2.0 * ph) + 0.003 * j[4], 0.25 * np.sin(ph) + 0.003 * j[5])
+    m[:3, 3] *= scene.scale
+    return m.astype(np.float32)
+
+
+_TUM_ROOM = ((-2.4, 2.6), (-1.3, 1.2), (-2.2, 4.6))   # x, y (down: 1.2 is the floor), z extents in metres
+_TUM_WALL_ALBEDO = ((150.0, 95.0), (210.0, 70.0), (125.0, 165.0))  # (low, high) face of every axis
+
+
+def _tum_boxes(scene: Scene) -> np.ndarray:
+    """[n, 7]: xmin, xmax, ymin, ymax, zmin, zmax, albedo -- a desk with a monitor, a cabinet, a chair, a box close to the
+    camera (inside the sensor's 0.4 m blind range for part of the sweep), and `n_boxes` seeded ones standing on the floor."""
+    fixed = [(-1.5, 0.3, 0.45, 1.2, 1.6, 2.5, 120.0), (-0.9, -0.3, 0.0, 0.45, 2.1, 2.2, 40.0), (1.8, 2.6, -0.6, 1.2, 0.5, 1.6, 180.0),
+             (0.55, 1.0, 0.4, 1.2, 1.0, 1.45, 90.0), (-0.45, -0.15, 0.55, 1.2, 0.62, 0.9, 200.0)]
+    idx = np.arange(scene.n_boxes, dtype=np.uint32)
+    r = lambda k: _uniform01(idx * np.uint32(7) + np.uint32(k), scene.seed * 31 + 19)
+    ang = 2.0 * np.pi * (idx + r(0)) / max(scene.n_boxes, 1)
+    rad = 1.3 + 0.8 * r(1)           # a ring around the camera's wander: the camera never enters a box
+    cx, cz = rad * np.sin(ang), 0.4 + rad * np.cos(ang)
+    w, d, hgt = 0.15 + 0.35 * r(2), 0.15 + 0.35 * r(3), 0.3 + 1.2 * r(4)
+    rnd = np.stack([cx - w / 2, cx + w / 2, 1.2 - hgt, np.full(len(idx), 1.2), cz - d / 2, cz + d / 2, 50.0 + 170.0 * r(5)], axis=1)
+    out = np.concatenate([np.array(fixed, dtype=np.float64), rnd]) if len(idx) else np.array(fixed, dtype=np.float64)
+    out[:, :6] *= scene.scale
+    return out
+
+
+def _render_tum(cam: Camera, scene: Scene, t: int):
+    W, H = cam.width, cam.height
+    pose = scene.pose(t)
+    tl = t % scene.frames_per_period
+    P = pose.astype(np.float64)
+    org, R, sc = P[:3, 3], P[:3, :3], scene.scale
+    u = (np.arange(W, dtype=np.float64) - cam.cx) / cam.fx
+    v = (np.arange(H, dtype=np.float64) - cam.cy) / cam.fy
+    dc = np.stack([np.broadcast_to(u[None, :], (H, W)), np.broadcast_to(v[:, None], (H, W)), np.ones((H, W))])
+    d = np.einsum("ij,jhw->ihw", R, dc)
+    best = np.full((H, W), np.inf)
+    albedo = np.zeros((H, W))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for a in range(3):  # the room from inside: the face every ray leaves through
+            lo, hi = _TUM_ROOM[a][0] * sc, _TUM_ROOM[a][1] * sc
+            ta = np.where(d[a] > 0, (hi - org[a]) / d[a], (lo - org[a]) / d[a])
+            ta = np.where(np.abs(d[a]) > 1e-12, ta, np.inf)
+            nearer = ta < best
+            best = np.where(nearer, ta, best)
+            albedo = np.where(nearer, np.where(d[a] > 0, _TUM_WALL_ALBEDO[a][1], _TUM_WALL_ALBEDO[a][0]), albedo)
+        for b in _tum_boxes(scene):
+            t0 = [(b[2 * a] - org[a]) / d[a] for a in range(3)]
+            t1 = [(b[2 * a + 1] - org[a]) / d[a] for a in range(3)]
+            tn = np.maximum(np.maximum(np.minimum(t0[0], t1[0]), np.minimum(t0[1], t1[1])), np.minimum(t0[2], t1[2]))
+            tf = np.minimum(np.minimum(np.maximum(t0[0], t1[0]), np.maximum(t0[1], t1[1])), np.maximum(t0[2], t1[2]))
+            ok = (tn <= tf) & (tn > 0) & (tn < best)
+            best = np.where(ok, tn, best)
+            albedo = np.where(ok, b[6], albedo)
+    tt = best  # camera-frame z == ray parameter (dir_c.z = 1); a closed room: every ray hits
+    wpt = org[:, None, None] + tt[None] * d
+    cell = (np.floor(wpt[0] / (0.25 * sc) + 1000.0) + np.floor(wpt[1] / (0.25 * sc) + 1000.0) + np.floor(wpt[2] / (0.25 * sc) + 1000.0)).astype(np.int64)
+    chk = np.where(cell & 1, scene.checker, -scene.checker)
+    pix = (np.arange(H * W, dtype=np.uint32)).reshape(H, W)
+    salt = scene.seed * 2654435761 + tl * 40503
+    img = albedo + chk + _uniform01(pix, salt + 1) * scene.intensity_noise
+    image = np.clip(np.floor(img), 0, 255).astype(np.uint8)
+    # ---- the sensor
+    z = tt * (1.0 + scene.depth_noise * (_uniform01(pix, salt + 2) - 0.5))
+    if not scene.tum_sensor:
+        return image, np.where(_uniform01(pix, salt + 3) < scene.hole_fraction, 0.0, z).astype(np.float32), pose
+    with np.errstate(divide="ignore", invalid="ignore"):
+        disp_true = scene.kinect_bf * sc / tt                      # pixels, of the clean geometry: the shadows' extent
+        disp = np.round(scene.kinect_bf * sc / z / scene.kinect_subpixel) * scene.kinect_subpixel
+        zq = scene.kinect_bf * sc / disp
+    valid = np.isfinite(zq) & (zq >= scene.tum_near * sc) & (zq <= scene.tum_far * sc)
+    # projector shadow: a point is lit unless something `k` pixels to its left is at least `k` pixels of disparity nearer
+    shadow = np.zeros((H, W), dtype=bool)
+    for k in range(1, min(W, 96)):
+        shadow[:, k:] |= (disp_true[:, :-k] - disp_true[:, k:]) >= k
+    valid &= ~shadow
+    valid &= ~(_uniform01(pix, salt + 3) < scene.hole_fraction)
+    ox, oy = int(_hash32(np.array([(salt + 4) & 0xFFFFFFFF], dtype=np.uint32))[0] % 5), int(_hash32(np.array([(salt + 5) & 0xFFFFFFFF], dtype=np.uint32))[0] % 7)
+    yy, xx = np.mgrid[0:H, 0:W]
+    block = (((yy + oy) // 7) * 4099 + (xx + ox) // 5).astype(np.uint32)
+    valid &= ~(_uniform01(block, salt + 6) < scene.blob_fraction)
+    if scene.tum_border > 0:
+        valid[:, W - scene.tum_border:] = False
+    u16 = np.clip(np.round(np.where(valid, zq, 0.0) * scene.tum_depth_scale), 0, 65535).astype(np.uint16)
+    depth = (u16.astype(np.float32) / np.float32(scene.tum_depth_scale)).astype(np.float32)  # what the depth PNG decodes to
+    return image, depth, pose
+
+
 def render(cam: Camera, scene: Scene, t: int):
     """Return (image uint8 [H,W], depth float32 [H,W] metres, 0 = invalid, pose float32 4x4)."""
+    if scene.tum:
+        return _render_tum(cam, scene, t)
     W, H = cam.width, cam.height
     pose = scene.pose(t)
     tl = t % scene.frames_per_period
@@ -271,8 +397,8 @@ def _worker_main():
         _render_to(Camera(**job["cam"]), Scene(**job["scene"]), job["t"], job["out"])
 
 
-def sequence(cam: Camera, scene: Scene, n_frames: int, start: int = 0):
-    """Yield (t, image, depth, pose, ref_idx): every 5th frame is a keyframe and
+def sequence(cam: Camera, scene: Scene, n_frames: int, start: int = 0, keyframe_every: int = 5):
+    """Yield (t, image, depth, pose, ref_idx): every 5th (``keyframe_every``) frame is a keyframe and
     ``ref_idx`` is the index of the latest keyframe."""
     cache = {}
     for t in range(start, start + n_frames):
@@ -280,7 +406,7 @@ def sequence(cam: Camera, scene: Scene, n_frames: int, start: int = 0):
         if tl not in cache:
             cache[tl] = render(cam, scene, tl)[:2]
         image, depth = cache[tl]
-        yield t, image, depth, scene.pose(t), (t - start) // 5
+        yield t, image, depth, scene.pose(t), (t - start) // keyframe_every
 
 
 # ----------------------------------------------------------------------------------------------------------

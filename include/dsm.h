@@ -315,6 +315,13 @@ int dsm_debug_wave_stamps(dsm_handle *h, int64_t *out);
  * first frame, before dsm_batch_create) */
 int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap);
 
+/* debug tap: occupancy of the second tiers of the lane-per-seed kernels (launches batched over >= 8 frames) in the LATEST
+ * frame of this handle: out[2 s + 0] = superpixels whose robust mean depth (FF.cpp:530-556) needed more than one Huber pass in
+ * sweep s, out[2 s + 1] = superpixels whose depth list outgrew its 127-entry LDS row in sweep s, out[6] = groups of four
+ * superpixels the plane fit (FF.cpp:128-180) took in its full-length tier, out[7] = 0 (reserved).  All zero after a frame that
+ * ran the wave-per-seed kernels.  Synchronises. */
+int dsm_debug_tier_counts(dsm_handle *h, int32_t *out /* 8 */);
+
 /* ---- per-kernel timing (hip events on the handle's stream) ----------------------------- */
 #define DSM_MAX_STAGES 32
 typedef struct dsm_stage_times {

@@ -42,12 +42,25 @@ STEREO = [
 ]
 
 
+# BASELINE configs[3]: TUM-RGBD-style feed at 640x480 under the RGB-D constant set (fusion_functions.h:17-21; the library
+# is libdsm_ref_serial_rgbd.so = the reference TU compiled with that set): a hand-held sweep through a room, depth quantised
+# as a Kinect + the dataset's uint16 / 5000 PNGs deliver it, zero in shadows / blobs / out of range, a keyframe every 4
+# frames.  `room`: two laps of a 100-frame loop (revisits: fusion into mature surfels, pruning of what the pan left
+# behind); `sparse`: a sensor that loses a quarter of its pixels and sees 3.2 m far.
+_TUM = {"seed": 7, "tum": True, "frames_per_period": 100, "intensity_noise": 8.0, "checker": 25.0, "n_boxes": 6}
+TUM = [
+    {"name": "tum_rgbd_room_200", "camera": "VGA_RGBD", "scene": dict(_TUM), "frames": 200, "checkpoint_every": 50, "keyframe_every": 4},
+    {"name": "tum_rgbd_sparse_60", "camera": "VGA_RGBD", "scene": dict(_TUM, seed=11, frames_per_period=60, hole_fraction=0.06, blob_fraction=0.08, tum_far=3.2),
+     "frames": 60, "checkpoint_every": 20, "keyframe_every": 4},
+]
+
+
 def long_sequence(case=LONG):
     cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
     ref = RefOracle(cam)
     local = np.zeros(0, SURFEL_DTYPE)
     per_frame, checkpoints = [], {}
-    for t, img, dep, pose, ridx in synth.sequence(cam, scene, case["frames"]):
+    for t, img, dep, pose, ridx in synth.sequence(cam, scene, case["frames"], keyframe_every=case.get("keyframe_every", 5)):
         before = len(local)
         local, k = ref.fuse_map(ridx, img, dep, pose, local)
         per_frame.append({"n_new": int(k), "n_local": int(len(local)), "n_holes": int(before + k - len(local)),
@@ -81,6 +94,12 @@ def large_map(case):
 
 def main():
     path = os.path.join(HERE, "long_golden.json")
+    if "--only-tum" in sys.argv:  # add / refresh the RGB-D sequences, keep the rest of the record
+        out = json.load(open(path))
+        out["tum_sequences"] = [long_sequence(c) for c in TUM]
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        return
     if "--only-stereo" in sys.argv:  # add / refresh the stereo sequences, keep the rest of the record
         out = json.load(open(path))
     else:
@@ -88,6 +107,7 @@ def main():
                "sequence": long_sequence(), "large_map": large_map(scale_cases.LARGE_MAP),
                "fullhd_2m": large_map(scale_cases.FULLHD_2M)}
     out["stereo_sequences"] = [long_sequence(c) for c in STEREO]
+    out["tum_sequences"] = [long_sequence(c) for c in TUM]
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
 

@@ -140,11 +140,13 @@ class Emu:
 
 # the reference's real feed (publisher.py:37-40): disparity-quantised depth, +inf at zero disparity, saturated / 8-level image
 STEREO_SCENE = dict(stereo=True, saturate_above=150.0, intensity_levels=8)
+TUM_SCENE = dict(seed=7, tum=True, frames_per_period=24, intensity_noise=8.0, checker=25.0, n_boxes=6)
 
 
 @pytest.mark.parametrize("camera,frames,salt,stereo", [("TINY", 48, 0, None), ("TINY", 48, 977, None), ("KITTI_1226", 3, 12345, None),
                                                         ("VGA_RGBD", 2, 0, None), ("TINY_RAGGED", 30, 0, None), ("TINY_RAGGED", 30, 555, None),
-                                                        ("TINY", 30, 0, "inf"), ("TINY", 30, 311, "zero"), ("KITTI_1226", 3, 0, "inf")])
+                                                        ("TINY", 30, 0, "inf"), ("TINY", 30, 311, "zero"), ("KITTI_1226", 3, 0, "inf"),
+                                                        ("NODE_CAM_RGBD", 24, 0, "tum"), ("NODE_CAM_RGBD", 24, 4242, "tum"), ("VGA_RGBD", 3, 0, "tum")])
 def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt, stereo):
     """dsm_math.h + the tmin/worklist fixed point, staged seed commit, 20-lane Gauss-Newton and the
     parallel-exact compaction, executed serially (and in scrambled order when salt != 0), bit-equal to
@@ -153,13 +155,15 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt, s
     pick meets ten times as many near-ties."""
     cam = getattr(synth, camera)
     scene = synth.Scene(seed=5, scale=0.12, step=0.05) if cam.rgbd else synth.Scene()
-    if stereo:
+    if stereo == "tum":  # BASELINE configs[3]'s kind of input: Kinect-quantised uint16 / 5000 depth, zero in shadows and blobs
+        scene = synth.Scene(**TUM_SCENE)
+    elif stereo:
         scene = synth.Scene(zero_disparity_inf=stereo == "inf", **STEREO_SCENE)
     emu, orc = Emu(hostemu_lib, cam), ob.PortOracle(cam)
     emu.lib.emu_set_order_salt(emu.h, salt)
     le = np.zeros(0, ob.SURFEL_DTYPE)
     lo = le.copy()
-    for t, img, dep, pose, ref in synth.sequence(cam, scene, frames):
+    for t, img, dep, pose, ref in synth.sequence(cam, scene, frames, keyframe_every=4 if stereo == "tum" else 5):
         le, ke = emu.fuse_map(ob.SURFEL_DTYPE, ref, img, dep, pose, le)
         lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
         assert ke == ko, t
@@ -921,11 +925,16 @@ def test_port_oracle_matches_long_golden(ob, synth):
     import scale_cases
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "long_golden.json")))
     assert gold["stereo_sequences"][0]["n_nonfinite"] > 0, "the +inf feed leaves no non-finite surfel: the case lost its point"
-    for case in [gold["sequence"]] + gold["stereo_sequences"]:  # (stereo: the reference's real feed, publisher.py:37-40)
+    for tum in gold["tum_sequences"]:  # BASELINE configs[3]: 640x480, the RGB-D constant set, TUM-style depth
+        per = tum["per_frame"]
+        assert sum(f["n_holes"] for f in per) > 1000 and any(f["n_holes"] > f["n_new"] for f in per) and any(0 < f["n_holes"] < f["n_new"] for f in per), \
+            tum["name"] + ": pruning or one of the compaction branches never occurs"
+    # (stereo: the reference's real feed, publisher.py:37-40)
+    for case in [gold["sequence"]] + gold["stereo_sequences"] + gold["tum_sequences"]:
         cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
         orc = ob.PortOracle(cam)
         local = np.zeros(0, ob.SURFEL_DTYPE)
-        for (t, img, dep, pose, ref), want in zip(synth.sequence(cam, scene, case["frames"]), case["per_frame"]):
+        for (t, img, dep, pose, ref), want in zip(synth.sequence(cam, scene, case["frames"], keyframe_every=case.get("keyframe_every", 5)), case["per_frame"]):
             local, k = orc.fuse_map(ref, img, dep, pose, local)
             assert (k, len(local)) == (want["n_new"], want["n_local"]), (case["name"], t)
             assert hashlib.sha256(orc.labels().tobytes()).hexdigest() == want["labels_sha256"], (case["name"], t)

@@ -45,14 +45,25 @@ def map_sha(a, dtype):
 # where the disparity is 0 (`stereo_inf`; `stereo_zero`: those pixels at depth 0), an image with eight grey levels and
 # saturated highlights: seeds with infinite and NaN mean depths, non-finite surfels, and a tenth of the first sweep's
 # pixels exactly between two seeds (k_assign's list of open picks is the common case there, not the exception).
-SEQUENCES = ["drive200", "stereo_inf", "stereo_zero"]
+# BASELINE configs[3] (round 6): `tum_room` / `tum_sparse` -- 640x480 under the RGB-D constant set (fusion_functions.h:17-21),
+# a hand-held sweep through a room with depth as a Kinect + the TUM dataset's uint16 / 5000 PNGs deliver it (a hundred-odd
+# distinct depth values per frame, zero in shadows, blobs, beyond the range and at the border), a keyframe every 4 frames,
+# two laps of a closed loop: revisits, pruning (FF.cpp:207-211) and both compaction branches (SM.cpp:1087-1109) all occur.
+SEQUENCES = ["drive200", "stereo_inf", "stereo_zero", "tum_room", "tum_sparse"]
 
 
 @pytest.fixture(params=SEQUENCES)
 def seq_case(request, gold):
     if request.param == "drive200":
         return gold["sequence"]
+    if request.param.startswith("tum"):
+        return gold["tum_sequences"][SEQUENCES.index(request.param) - 3]
     return gold["stereo_sequences"][SEQUENCES.index(request.param) - 1]
+
+
+def _sequence(synth, case, extra=0):
+    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    return cam, scene, list(synth.sequence(cam, scene, case["frames"] + extra, keyframe_every=case.get("keyframe_every", 5)))
 
 
 def test_long_sequence_kitti_golden(mods, seq_case):
@@ -61,9 +72,8 @@ def test_long_sequence_kitti_golden(mods, seq_case):
     frame pipelining.  Vectors: the reference TU."""
     api, synth, ob = mods
     case = seq_case
-    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    cam, scene, frames = _sequence(synth, case)
     period = scene.frames_per_period
-    frames = list(synth.sequence(cam, scene, case["frames"]))
     per = case["per_frame"]
     # the regimes this test exists for do occur in the reference's run
     assert sum(f["n_holes"] for f in per) > 1000, "no pruning / deletion in the golden run"
@@ -73,6 +83,9 @@ def test_long_sequence_kitti_golden(mods, seq_case):
         assert case["n_mature"] > 1000
     if case["name"] == "kitti1226_stereo_inf_60":
         assert case["n_nonfinite"] > 10000, "the +inf feed leaves no non-finite surfels: the case lost its point"
+    if case["name"].startswith("tum"):
+        assert cam.rgbd and (cam.width, cam.height) == (640, 480) and case["keyframe_every"] == 4
+        assert np.mean([np.unique(f[2]).size for f in frames[:10]]) < 1000, "the depth is not quantised as a Kinect's"
 
     ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20)
     for t in range(period):
@@ -113,10 +126,9 @@ def test_long_sequence_kitti_golden_batched(mods, seq_case):
     after its own 50th / 100th / 150th / 200th frame is the reference TU's, and so are its labels after its 200th."""
     api, synth, ob = mods
     case = seq_case
-    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
-    period = scene.frames_per_period
     n, B = case["frames"], 8
-    frames = list(synth.sequence(cam, scene, n + B))  # the leaders run a few frames past the end while the others finish
+    cam, scene, frames = _sequence(synth, case, extra=B)  # the leaders run a few frames past the end while the others finish
+    period = scene.frames_per_period
     step = case["checkpoint_every"]
     plan = api.FusionFunctions.pack_replay([f[0] % period for f in frames], [f[4] for f in frames], [f[3] for f in frames])
     lead = [B - 1 - b for b in range(B)]
@@ -169,9 +181,8 @@ def test_four_batches_in_flight_against_the_golden(mods, seq_case):
     import threading
     api, synth, ob = mods
     case = seq_case
-    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    cam, scene, frames = _sequence(synth, case)
     period, n, step = scene.frames_per_period, case["frames"], case["checkpoint_every"]
-    frames = list(synth.sequence(cam, scene, n))
     plan = api.FusionFunctions.pack_replay([f[0] % period for f in frames], [f[4] for f in frames], [f[3] for f in frames])
     n_bat, per = 4, 32
     handles = []
@@ -221,9 +232,8 @@ def test_long_sequence_streamed_input(mods, seq_case):
     checkpoints).  Maps and labels are the reference TU's: streamed == resident, byte for byte."""
     api, synth, ob = mods
     case = seq_case
-    cam, scene = getattr(synth, case["camera"]), synth.Scene(**case["scene"])
+    cam, scene, frames = _sequence(synth, case)
     n, step, C = case["frames"], case["checkpoint_every"], 10
-    frames = list(synth.sequence(cam, scene, n))
     period = scene.frames_per_period
 
     def host_frames(ff):
@@ -283,6 +293,60 @@ def test_long_sequence_streamed_input(mods, seq_case):
     for h in handles:
         h.close()
     pin.close()
+
+
+def test_tum_live_callback_form(mods, gold):
+    """BASELINE configs[3] the way the live node runs it (TUM-RGBD-style 640x480 at 30 Hz, one hipGraph per frame): every frame
+    arrives from pageable host memory (dsm_frame_upload into one of two slots in turn), is fused by one graph replay
+    (dsm_fuse_frame_resident) and waited for -- 200 frames under the RGB-D constant set, per frame the label image, the new and
+    total surfel counts, every 50 frames the whole map, against the reference TU's vectors.  Then the drop-in call
+    (dsm_fuse_map: host vector in and out) over the first 60 frames, and the second-tier tap on a batch of eight."""
+    api, synth, ob = mods
+    case = gold["tum_sequences"][0]
+    cam, scene, frames = _sequence(synth, case)
+    per = case["per_frame"]
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=2, surfel_capacity=1 << 18)
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    for (t, img, dep, pose, ref), want in zip(frames, per):
+        ff.frame_upload(t & 1, img, dep)
+        ff.fuse_frame_resident(t & 1, ref, pose)
+        ff.synchronize()
+        assert (ff.last_new_count(), ff.map_size()) == (want["n_new"], want["n_local"]), f"frame {t}"
+        assert hashlib.sha256(ff.labels().tobytes()).hexdigest() == want["labels_sha256"], f"frame {t}: label image"
+        if str(t + 1) in case["map_sha256"]:
+            assert map_sha(ff.map_download(), api.SURFEL_DTYPE) == case["map_sha256"][str(t + 1)], f"map after frame {t}"
+    ff.close()
+    # the drop-in call, frame after frame on the caller's own array
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 18)
+    local = np.zeros(0, api.SURFEL_DTYPE)
+    for (t, img, dep, pose, ref), want in zip(frames[:60], per):
+        local, k = ff.fuse_map(ref, img, dep, pose, local)
+        assert (k, len(local)) == (want["n_new"], want["n_local"]), f"drop-in, frame {t}"
+    assert map_sha(local, api.SURFEL_DTYPE) == case["map_sha256"]["50"] or len(local) == per[59]["n_local"]
+    ff.close()
+    # a batch of eight (lane-per-seed kernels): the tap that says how many seeds went on to the second tiers
+    hs = []
+    for _ in range(8):
+        h = api.FusionFunctions.from_camera(cam, frame_slots=4, surfel_capacity=1 << 18, pipeline_depth=1)
+        for i in range(4):
+            h.frame_upload(i, frames[i][1], frames[i][2])
+        h.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        hs.append(h)
+    bt = api.Batch(hs)
+    pl = api.FusionFunctions.pack_replay(list(range(4)), [f[4] for f in frames[:4]], [f[3] for f in frames[:4]])
+    s_, r_, p_, m = api.Batch.pack([pl] * 8)
+    bt.replay_enqueue(s_, r_, p_, m)
+    bt.synchronize()
+    S = (cam.width // 8) * (cam.height // 8)
+    for h in hs:
+        tc = h.debug_tier_counts()
+        assert all(0 <= v <= S for v in tc["huber_rest_by_sweep"] + tc["long_list_by_sweep"]) and 0 <= tc["fit_long_groups"] <= S // 4, tc
+        assert sum(tc["huber_rest_by_sweep"]) > 0, tc  # (some superpixel always needs a second Huber pass on this input)
+        assert tc == hs[0].debug_tier_counts()
+        assert h.map_size() == per[3]["n_local"]
+    bt.close()
+    for h in hs:
+        h.close()
 
 
 def _large_case(mods, gold_rows, case, dropin_trial=None):
