@@ -234,7 +234,7 @@ def oracle_replay_worker(spec_json):
     per = spec["period"]
     frames = synth.render_many([(cam, scene, i) for i in range(per)], workers=1)  # (rendered and cached by the parent already)
     orc, lo = PortOracle(cam), np.zeros(0, O_DTYPE)
-    for t in range(spec["frames"]):
+    for t in range(spec["frames"]):  # (keyframe indices count from the subsequence's first frame; `phase` = where in the scene it starts)
         img, dep = frames[(t + spec["phase"]) % per]
         lo, _ = orc.fuse_map(t // 5, img, dep, scene.pose(t + spec["phase"]), lo)
     print(json.dumps({"subsequence": spec["subsequence"], "frames": spec["frames"], "surfels": int(len(lo)),
@@ -347,6 +347,174 @@ def self_launch(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+def open_group(args, world, rank, local_rank):
+    """Device of this rank and the process group of the final merge -> (torch, device, dist or None, device of the collectives'
+    tensors, why there is no group).  DSM_BENCH_BACKEND=gloo + DSM_BENCH_ONE_DEVICE=1 run the multi-rank logic on a single GPU
+    (tests only): every rank uses cuda:0 and the collectives run on CPU tensors."""
+    import torch
+    backend = os.environ.get("DSM_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("DSM_BENCH_ONE_DEVICE", "0") == "1"
+    device = 0 if (world == 1 or one_device) else local_rank
+    torch.cuda.set_device(device)
+    # At --gpus 1 too (a group of one on a loopback port): the merge of the final clouds then goes through RCCL on the one GPU
+    # -- ncclCommInitRank, the all-gather of the counts, the all-gather of the padded cloud -- exactly as it does on a node;
+    # nothing of it is inside the timed region.
+    dist, group_error = None, None
+    if world > 1 or not args.no_rccl_world1:
+        from densesurfelmapping_amd.replay import init_collective
+        try:
+            dist = init_collective(backend, world, rank, device)
+        except Exception as e:  # noqa: BLE001 -- a group of one is an extra; a world of several cannot do without
+            if world > 1:
+                raise
+            group_error = repr(e)[:300]
+    coll_dev = f"cuda:{device}" if backend == "nccl" else "cpu"
+    if world > 1:
+        if not one_device and torch.cuda.device_count() < world:
+            sys.exit(f"bench.py: rank {rank} sees {torch.cuda.device_count()} GPUs for a world of {world}")
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+    return torch, device, dist, coll_dev, group_error
+
+
+def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
+    """`--workload sharded`: BASELINE configs[2] as the north star states it.  One synthetic KITTI-shaped sequence of
+    world x (W + K) x F frames is cut into `world` contiguous subsequences (replay.shard_subsequences); rank r streams ITS
+    subsequence from page-locked host memory through ONE handle (replay.HipEngine: pipeline depth 24, chunks of 48 frames on
+    the device's upload stream beside the kernels of the chunk before, three groups of frame slots in turn), keyframe indices
+    restarting at its first frame, the map resident; the final clouds are merged by one all-gather of the counts and one of the
+    padded clouds (RCCL).  A step = F frames of every rank's subsequence; the warm-up steps are replayed first (same engine,
+    same map), the K timed steps between two barriers as ONE streamed replay.  Rank 0's final map is checked against the CPU
+    oracle's replay of the same subsequence, started beside the GPU work."""
+    import hashlib
+    import torch
+    from densesurfelmapping_amd import api, synth, replay as rp
+    K, W, F = args.steps, args.warmup, args.frames_per_step
+    per_rank = (W + K) * F
+    shards = rp.shard_subsequences(world * per_rank, world)
+    a, b = shards[rank]
+    oracle_job, spec = None, None
+    if rank == 0 and not args.no_verify and per_rank <= 1600:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+        spec = {"subsequence": 0, "camera": "KITTI_1226", "seed": 12345, "period": 50, "phase": a, "frames": per_rank}
+    if world > 1 and rank != 0:
+        dist.barrier()  # rank 0 renders the scene's period (cached in /tmp), the others read it
+    t_r = time.perf_counter()
+    src = rp.SyntheticSource(world * per_rank, camera="KITTI_1226", seed=12345, prerender=True)
+    render_s = time.perf_counter() - t_r
+    if world > 1 and rank == 0:
+        dist.barrier()
+    if spec:
+        oracle_job = start_oracle_replays([spec])[0]
+    cam = src.cam
+    eng = rp.HipEngine(cam, device=device, capacity=1 << 21, pipeline_depth=args.pipeline_depth or 24, chunk=48)
+    if W:
+        eng.replay(src, a, a + W * F, origin=a)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.replay(src, a + W * F, b, origin=a)  # (returns when the device has finished)
+    torch.cuda.synchronize()
+    dt_mine = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    st = dict(eng.stats)
+    rank_fps = [K * F / dt_mine]
+    if world > 1:
+        mine = torch.tensor([dt_mine, dt], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_fps = [K * F / float(t_[0].item()) for t_ in every]
+        dt = max(float(t_[1].item()) for t_ in every)
+    n_final = eng.ff.map_size()
+    got = eng.cloud() if spec else None
+    merge_s, counts = None, [n_final]
+    if dist is not None:
+        cloud = eng.cloud_tensor(torch, f"cuda:{device}").to(coll_dev)
+        try:
+            rp.merge_clouds(cloud[:44])  # communicator warm-up
+            torch.cuda.synchronize()
+            t_m = time.perf_counter()
+            merged, counts = rp.merge_clouds(cloud)
+            torch.cuda.synchronize()
+            merge_s = time.perf_counter() - t_m
+            assert counts[rank] == n_final and merged.numel() == 44 * sum(counts)
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                raise
+            group_error, dist = "merge failed: " + repr(e)[:300], None
+    n_pix, n_seed = cam.width * cam.height, (cam.width // 8) * (cam.height // 8)
+    fps = world * K * F / dt
+    out = {"metric": "depth frames fused/sec @ KITTI 1226x370", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+           "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: one KITTI-shaped 1226x370 sequence split into one contiguous subsequence per GPU, every rank's frames "
+                                  "streamed from page-locked host memory through one handle (frame groups), map resident, RCCL all-gather of the final clouds",
+                      "frames_per_rank_per_step": F, "frames_per_rank": per_rank, "timed_frames_per_rank": K * F, "shards": [list(s_) for s_ in shards],
+                      "pipeline_depth": args.pipeline_depth or 24, "chunk_frames": 48, "frame_slot_groups": rp.HipEngine.GROUPS,
+                      "host_to_device_GBps_per_rank": round(st["frames"] * st["bytes_per_frame"] / st["seconds"] / 1e9, 2),
+                      "frames_already_page_locked": st["zero_copy"], "timed_seconds": round(dt, 4), "host_render_seconds": round(render_s, 1),
+                      "final_surfels_all_ranks": int(sum(counts)),
+                      "parallelism": f"{world} GPU x 1 streamed subsequence, all-gather of final cloud only",
+                      "pcie_note": "inputs are NOT resident when the clock starts: every timed frame crosses the host link inside the timed region "
+                                   "(the resident-input headline is --workload headline)"}}
+    if dist is None:
+        out["multi_gpu"] = {"world_size_seen_by_backend": None, "backend": None, "note": "no process group: " + (group_error or "--no-rccl-world1")}
+    else:
+        out["multi_gpu"] = {"world_size_seen_by_backend": dist.get_world_size(), "backend": dist.get_backend(),
+                            "per_rank_frames_per_s": [round(v, 1) for v in rank_fps], "min_rank_frames_per_s": round(min(rank_fps), 1),
+                            "max_rank_frames_per_s": round(max(rank_fps), 1), "final_cloud_all_gather_ms": round(merge_s * 1e3, 3),
+                            "final_cloud_bytes_all_ranks": int(sum(counts)) * 44, "per_rank_surfels": [int(c) for c in counts]}
+    if rank == 0 and not args.no_roofline:
+        # the dominant stage launched for ONE frame (HIP events on the handle's stream, eager replay): the frame groups of the
+        # timed region launch it for eight frames at a time, for which the library has no event-timed form
+        ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=50, surfel_capacity=1 << 21)
+        for i, (img, dep) in enumerate(src._period):
+            ff.frame_upload(i, img, dep)
+        ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+        n_ev = min(48, per_rank)
+        plan = api.FusionFunctions.pack_replay([t % 50 for t in range(a, a + n_ev)], [t // 5 for t in range(n_ev)], np.stack([src.pose(t) for t in range(a, a + n_ev)]))
+        stages, nfr = ff.replay_timed(*plan)
+        ovh = ff.event_overhead_ms * 1e3
+        per = {k: max(v[0] / max(v[1], 1) * 1e3 - ovh, 0.0) for k, v in stages.items()}
+        dom = [k for k in per if k.startswith("update_seeds")]
+        dom_us = float(np.mean([per[k] for k in dom]))
+        alg = stage_alg_bytes("update_seeds_0", n_pix, n_seed, ff.timed_mean_local, ff.timed_mean_new)
+        traffic, tsrc = pmc_traffic("k_update_seeds", PMC_TRAFFIC_SINGLE)
+        out["roofline"] = {"bound": "hbm", "kernel": "k_update_seeds_wave", "launches_per_frame": len(dom), "achieved": round(alg / dom_us / 1e3, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / dom_us / 1e3 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "traffic_source": f"profiles/{tsrc}" if tsrc else None, "alg_bytes_per_launch": int(alg), "avg_launch_us": round(dom_us, 2),
+                           "frames_timed": int(nfr),
+                           "note": "the dominant stage launched for one frame; the timed region launches the superpixel stages for eight consecutive "
+                                   "frames at a time (frame groups); e2e_hbm_frac is the whole streamed replay's"}
+        out["kernel_us"] = {k: round(v, 2) for k, v in per.items()}
+        ff.close()
+    if spec:
+        try:
+            so, _ = oracle_job.communicate(timeout=300)
+            rec = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+        except (subprocess.TimeoutExpired, IndexError, ValueError):
+            oracle_job.kill()
+            rec = None
+        same = bool(rec) and rec["surfels"] == len(got) and rec["sha256"] == hashlib.sha256(canon_bytes(got)).hexdigest()
+        out["verified"] = out["verified_timed_region"] = bool(same) if rec else None
+        out["verification"] = {"what": f"rank 0's final map (frames {a}..{b - 1} of the sequence from an empty map, warm-up and timed steps) against the "
+                                       "CPU oracle's replay of the same subsequence, NaN-canonical SHA-256 of the whole map",
+                               "surfels": int(len(got)), "oracle_surfels": rec["surfels"] if rec else None, "equal": same if rec else None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cam, src.scene, src._period, 50, W * F, per_rank)
+    m_mean = n_final / 2.0
+    out["e2e_hbm_frac"] = round(fps * (9 * n_pix + 60 * n_seed + 88 * m_mean + 44 * 1400.0) / 1e9 / (HBM_PEAK_GBS * world), 5)
+    eng.close()
+    src.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        if world > 1:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,8 +522,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSM_BENCH_STREAMS", "0")),
                     help=f"independent subsequences (handles) per GPU; 0 = {DEFAULT_SUBSEQUENCES} in batched mode, 8 in streams mode")
-    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSM_BENCH_FRAMES_PER_STEP", "32")),
-                    help="frames every subsequence advances per step")
+    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSM_BENCH_FRAMES_PER_STEP", "0")),
+                    help="frames every subsequence advances per step (0 = 32; 48, one upload chunk, with --workload sharded)")
     ap.add_argument("--mode", choices=("batched", "streams"), default=os.environ.get("DSM_BENCH_MODE", "batched"),
                     help="batched: the B subsequences advance in lockstep, one launch per kernel for all of them (dsm_batch_*); "
                          "streams: B handles on B streams, the hardware queues overlap their kernels (round 1's mode)")
@@ -372,8 +540,15 @@ def main():
     ap.add_argument("--legs", default=os.environ.get("DSM_BENCH_LEGS", "all"),
                     help="comma-separated legs beside the headline to run (single_sequence, dropin, fullhd, live, node, kitti_like, "
                          "streamed, sharded_replay, bounded_map, tum_like); default all")
+    ap.add_argument("--workload", choices=("headline", "sharded"), default=os.environ.get("DSM_BENCH_WORKLOAD", "headline"),
+                    help="headline: BASELINE configs[1], batched resident subsequences (weak scaling); sharded: BASELINE configs[2] itself -- ONE "
+                         "subsequence per GPU streamed from page-locked host memory through replay.HipEngine, all-gather of the final clouds")
+    ap.add_argument("--no-rccl-world1", action="store_true",
+                    help="--gpus 1: do not create the process group of one through which the final cloud merge runs on RCCL")
     ap.add_argument("--oracle-replay-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.frames_per_step <= 0:
+        args.frames_per_step = 48 if args.workload == "sharded" else 32
 
     if args.oracle_replay_worker:
         oracle_replay_worker(args.oracle_replay_worker)
@@ -389,6 +564,10 @@ def main():
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}), or let "
                  f"`python bench.py --gpus {args.gpus}` launch them")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload == "sharded":
+        _, device, dist, coll_dev, group_error = open_group(args, world, rank, local_rank)
+        sharded_workload(args, world, rank, device, dist, coll_dev, group_error)
+        return
     B, K, W, F = args.streams or (DEFAULT_SUBSEQUENCES if args.mode == "batched" else 8), args.steps, args.warmup, args.frames_per_step
     period = 50
     extras = rank == 0 and world == 1 and not args.no_dropin
@@ -445,7 +624,7 @@ def main():
     total_frames = (W + K) * F
     n_bat_plan = max(1, min(args.batches, B)) if args.mode == "batched" else 0
     oracle_jobs, oracle_specs = [], []
-    if rank == 0 and world == 1 and n_bat_plan and not args.no_verify and total_frames <= 1600:
+    if rank == 0 and n_bat_plan and not args.no_verify and total_frames <= 1600 and args.workload == "headline":  # (multi-rank runs too: rank 0's subsequences)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
         oracle_specs = [{"subsequence": g, "camera": "KITTI_1226", "seed": 12345 + 1000 * rank + 17 * scene_of[g], "period": period,
                          "phase": phase_of[g], "frames": total_frames} for g in range(n_bat_plan)]  # subsequence g = the first of batch g
@@ -454,23 +633,7 @@ def main():
     import torch
     from densesurfelmapping_amd import api
 
-    # DSM_BENCH_BACKEND=gloo + DSM_BENCH_ONE_DEVICE=1 run the multi-rank logic on a single GPU (tests only):
-    # every rank uses cuda:0 and the collectives run on CPU tensors.
-    backend = os.environ.get("DSM_BENCH_BACKEND", "nccl")
-    one_device = os.environ.get("DSM_BENCH_ONE_DEVICE", "0") == "1"
-    device = 0 if (world == 1 or one_device) else local_rank
-    torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":  # RCCL over xGMI
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend)
-    coll_dev = f"cuda:{device}" if backend == "nccl" else "cpu"
-    if world > 1:
-        if not one_device and torch.cuda.device_count() < world:
-            sys.exit(f"bench.py: rank {rank} sees {torch.cuda.device_count()} GPUs for a world of {world}")
-        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+    torch, device, dist, coll_dev, group_error = open_group(args, world, rank, local_rank)
 
     total = (W + K) * F
     lo_t, hi_t = W * F, total  # frame indices of the timed region, per subsequence
@@ -570,7 +733,8 @@ def main():
 
     # merge of the final clouds (outside the timed region): RCCL all-gather over xGMI
     merged_total = sum(m_end)
-    if world > 1:
+    merge_s = None
+    if dist is not None:
         from densesurfelmapping_amd.replay import merge_clouds
         clouds = []
         for ff, m in zip(handles, m_end):
@@ -578,13 +742,22 @@ def main():
             ff.map_copy_to_device(buf.data_ptr(), m)
             clouds.append(buf)
         mine = torch.cat(clouds).to(coll_dev)
-        merge_clouds(mine[:44])  # communicator warm-up (first-collective setup is not the merge)
-        torch.cuda.synchronize()
-        t_m = time.perf_counter()
-        merged, counts = merge_clouds(mine)
-        torch.cuda.synchronize()
-        merge_s = time.perf_counter() - t_m
-        merged_total = int(sum(counts))
+        del clouds
+        try:
+            merge_clouds(mine[:44])  # communicator warm-up (first-collective setup is not the merge)
+            torch.cuda.synchronize()
+            t_m = time.perf_counter()
+            merged, counts = merge_clouds(mine)
+            torch.cuda.synchronize()
+            merge_s = time.perf_counter() - t_m
+            assert world > 1 or (counts == [sum(m_end)] and torch.equal(merged, mine)), "a group of one must hand the cloud back unchanged"
+            merged_total = int(sum(counts))
+            del merged
+        except Exception as e:  # noqa: BLE001 -- at --gpus 1 the merge is an extra: report, do not lose the measurement
+            if world > 1:
+                raise
+            group_error, dist = "merge failed: " + repr(e)[:300], None
+        del mine
 
     for bt in batches:
         bt.close()
@@ -614,14 +787,18 @@ def main():
                    "mean_live_surfels": round(m_avg), "final_surfels_all_ranks": merged_total,
                    "parallelism": f"{world} GPU x {B} independent subsequences, all-gather of final cloud only"},
     }
-    if world > 1:
+    if dist is None:
+        out["multi_gpu"] = {"world_size_seen_by_backend": None, "backend": None,
+                            "note": "no process group: " + (group_error or "--no-rccl-world1")}
+    else:
         out["multi_gpu"] = {"world_size_seen_by_backend": dist.get_world_size(), "backend": dist.get_backend(),
                             "per_rank_frames_per_s": [round(v, 1) for v in rank_fps],
                             "min_rank_frames_per_s": round(min(rank_fps), 1), "max_rank_frames_per_s": round(max(rank_fps), 1),
                             "final_cloud_all_gather_ms": round(merge_s * 1e3, 3),
                             "final_cloud_bytes_all_ranks": int(merged_total) * 44,
                             "note": "value = frames of all ranks / the slowest rank's time between the barriers; the all-gather of "
-                                    "the final clouds (counts, then the padded clouds) is outside the timed region"}
+                                    "the final clouds (counts, then the padded clouds) is outside the timed region"
+                                    + ("; a group of ONE: the merge ran through RCCL on this GPU (library path exercised, no link crossed)" if world == 1 else "")}
 
     k_avg = None
     if rank == 0 and not args.no_roofline:
@@ -925,7 +1102,7 @@ def main():
                                          "loop closure with warp of active and inactive surfels at frame %d); host-inclusive" % period}
         node.close()
 
-    if rank == 0 and world == 1 and args.mode == "batched" and not args.no_verify:
+    if rank == 0 and args.mode == "batched" and not args.no_verify:  # (multi-rank runs too: a SCALE line is verified like a BENCH line)
         # What was timed, checked: fresh handles, the timed region's own form -- every batch of subsequences enqueued by
         # its own host thread on its own stream, all batches in flight at once -- over the first frames of every plan, and
         # the maps of one handle per batch against the CPU oracle's replay of the same frames (untimed; the oracle is the
@@ -1331,7 +1508,9 @@ def main():
         print(json.dumps(out))
     for ff in handles:
         ff.close()
-    if world > 1:
+    if dist is not None:
+        if world > 1:
+            dist.barrier()  # (rank 0 may still have been checking its maps against the oracle)
         dist.destroy_process_group()
 
 

@@ -158,7 +158,17 @@ class KittiSource:
             if self._pool is None:
                 self._pool = ProcessPoolExecutor(self.decode_workers, mp_context=mp.get_context("spawn"))
             load = functools.partial(kitti.load_frame, self.seq_dir, bf=self.bf)
-            for i, (image, depth) in zip(range(a, b), self._pool.map(load, range(a, b), chunksize=4)):
+            # a bounded window of decodes in flight (Executor.map would submit the whole range at once and buffer every result:
+            # a shard of decoded frames in RAM when the consumer is slower than the workers)
+            import collections
+            ahead = max(2, 4 * self.decode_workers)
+            pending, nxt = collections.deque(), a
+            while pending or nxt < b:
+                while nxt < b and len(pending) < ahead:
+                    pending.append((nxt, self._pool.submit(load, nxt)))
+                    nxt += 1
+                i, fut = pending.popleft()
+                image, depth = fut.result()
                 yield image, depth, self.poses[i].astype(np.float32)
             return
         for i in range(a, b):
@@ -167,7 +177,7 @@ class KittiSource:
 
     def close(self):
         if self._pool is not None:
-            self._pool.shutdown(wait=False, cancel_futures=True)
+            self._pool.shutdown(wait=True, cancel_futures=True)  # (at most `ahead` decodes are in flight: the wait is short)
             self._pool = None
 
 
@@ -204,8 +214,11 @@ class HipEngine:
         self.ff.fuse_frame_resident(slot, ref_idx, pose)
         self.n += 1
 
-    def replay(self, source, a, b, keyframe_every=KEYFRAME_EVERY):
-        """frames [a, b) of `source`, keyframe indices restarting at 0, streamed in chunks (see the class comment)"""
+    def replay(self, source, a, b, keyframe_every=KEYFRAME_EVERY, origin=None):
+        """frames [a, b) of `source`, streamed in chunks (see the class comment).  Keyframe indices count from frame `origin`
+        (default: a -- they restart at 0 with every call; a caller that replays one subsequence in several calls passes the
+        subsequence's first frame)"""
+        origin = a if origin is None else origin
         import queue
         import threading
         api, ff, C = self._api, self.ff, self.chunk
@@ -272,7 +285,7 @@ class HipEngine:
                     send(k + 1, (k + 1) % self.GROUPS)  # BEFORE chunk k is enqueued; ordered behind chunk k - 2, whose slots it overwrites
                 half = k % self.GROUPS
                 slots = [half * C + i for i in range(n)]
-                refs = [(t0 - a + i) // keyframe_every for i in range(n)]
+                refs = [(t0 - origin + i) // keyframe_every for i in range(n)]
                 ff.replay_enqueue(*ff.pack_replay(slots, refs, np.stack(poses_of.pop(k))))
                 if not zero_copy:
                     # page-locked blocks may be refilled once their transfers have landed: the newest upload is chunk
@@ -310,6 +323,25 @@ class HipEngine:
         self._pins = None
 
 
+def init_collective(backend, world, rank, device):
+    """The process group of the final merge.  world > 1: the launcher's rendezvous (MASTER_ADDR / MASTER_PORT).  world == 1:
+    a group of one on a loopback port of its own -- the merge then runs through the same library calls (RCCL's
+    ncclCommInitRank + ncclAllGather when the backend is "nccl") as on a node, on the one GPU there is."""
+    import torch
+    import torch.distributed as dist
+    kw = {}
+    if world == 1 and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            kw = {"init_method": f"tcp://127.0.0.1:{sk.getsockname()[1]}", "rank": 0, "world_size": 1}
+    if backend == "nccl":  # RCCL over xGMI
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device), **kw)
+    else:
+        dist.init_process_group(backend, **kw)
+    return dist
+
+
 def replay_shard(engine, source, a, b, keyframe_every=KEYFRAME_EVERY):
     """Frames [a, b) of `source` through `engine`, keyframe indices restarting at 0."""
     if hasattr(engine, "replay"):  # the HIP engine streams the shard in chunks
@@ -340,7 +372,8 @@ def run_rank(source, rank, world, *, engine_factory=None, backend="nccl", device
         os.makedirs(save_shards, exist_ok=True)
         np.save(os.path.join(save_shards, f"shard_{rank}.npy"), engine.cloud())
     t1 = time.perf_counter()
-    if world > 1:
+    import torch.distributed as dist
+    if world > 1 or (dist.is_available() and dist.is_initialized()):  # (a group of one: --merge-at-world1)
         merged, counts = merge_clouds(cloud, group)
     else:
         merged, counts = cloud, [cloud.numel() // SURFEL_BYTES]
@@ -352,7 +385,8 @@ def run_rank(source, rank, world, *, engine_factory=None, backend="nccl", device
     if hasattr(source, "close"):
         source.close()
     summary = {"rank": rank, "world": world, "frames": [a, b], "replayed": n, "surfels": counts[rank], "replay_s": round(t_replay, 3),
-               "frames_per_s": round(n / t_replay, 1) if t_replay > 0 else None, "merge_s": round(t_merge, 4), "backend": backend if world > 1 else None}
+               "frames_per_s": round(n / t_replay, 1) if t_replay > 0 else None, "merge_s": round(t_merge, 4),
+               "backend": (dist.get_backend(group) if dist.is_available() and dist.is_initialized() else None)}
     if stream_stats.get("seconds"):  # the streamed replay alone (without the final download of the cloud)
         summary["streamed"] = {"frames_per_s": round(stream_stats["frames"] / stream_stats["seconds"], 1),
                                "host_to_device_GBps": round(stream_stats["frames"] * stream_stats["bytes_per_frame"] / stream_stats["seconds"] / 1e9, 2),
@@ -401,6 +435,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI; gloo moves the clouds through host memory")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--merge-at-world1", action="store_true", help="--gpus 1: run the final merge through a process group of one (RCCL on the one GPU) instead of skipping it")
     ap.add_argument("--out", help="rank 0 writes the merged cloud here (.npy of 44-byte SurfelElement records)")
     ap.add_argument("--save-shards", metavar="DIR", help="every rank writes its own map to DIR/shard_<rank>.npy")
     args = ap.parse_args(argv)
@@ -419,15 +454,12 @@ def main(argv=None):
     source = KittiSource(args.kitti, args.poses, args.bf, args.frames, args.decode_workers) if args.kitti else SyntheticSource(args.synthetic, args.camera, args.seed, prerender=args.prerender)
     import torch
     torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group("gloo")
+    grouped = world > 1 or args.merge_at_world1
+    if grouped:
+        dist = init_collective(args.backend, world, rank, device)
     summary = run_rank(source, rank, world, backend=args.backend, device=device, save_shards=args.save_shards, out=args.out,
                        engine_options={"pipeline_depth": args.pipeline_depth, "chunk": args.chunk})
-    if world > 1:
+    if grouped:
         rows = [None] * world
         dist.all_gather_object(rows, summary)
         dist.destroy_process_group()

@@ -1107,29 +1107,106 @@ def test_replay_engine_streams_in_chunks(mods, depth, chunk):
         src.close()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_bench_ranks_on_one_gpu(world):
-    """bench.py's multi-rank path (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks, and with the
+@pytest.mark.parametrize("world,workload", [(2, "headline"), (8, "headline"), (2, "sharded"), (8, "sharded")])
+def test_bench_ranks_on_one_gpu(world, workload):
+    """bench.py's multi-rank paths (sharding, barriers, max-over-ranks timing, all-gather merge) with two ranks, and with the
     node's eight, sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL).  Launched
-    the way a user would: `python bench.py --gpus N` starts its own ranks."""
+    the way a user would: `python bench.py --gpus N` starts its own ranks.  `headline`: the weak-scaled batched replay;
+    `sharded`: BASELINE configs[2] itself -- one sequence cut into one streamed subsequence per rank.  A multi-rank line is
+    checked like a one-rank line: rank 0's maps of the TIMED run against the CPU oracle's replay of the same frames."""
     import subprocess
     import sys
     env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                        "--gpus", str(world), "--steps", "20" if world == 2 else "6", "--warmup", "5" if world == 2 else "2", "--streams", "2",
-                        "--frames-per-step", "4"],
+    if workload == "headline":
+        extra = ["--steps", "20" if world == 2 else "6", "--warmup", "5" if world == 2 else "2", "--streams", "2", "--frames-per-step", "4"]
+    else:
+        extra = ["--workload", "sharded", "--steps", "3", "--warmup", "1", "--frames-per-step", "24" if world == 2 else "13", "--no-roofline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra,
                        env=env, capture_output=True, text=True, timeout=900)
     out = _bench_line(r)
     assert out["n_gpus"] == world and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["final_surfels_all_ranks"] > 0
+    assert out["config"]["workload"].startswith("BASELINE configs[1]" if workload == "headline" else "BASELINE configs[2]")
     assert "cpu_baseline" not in out  # rank 0 at N=1 only
     mg = out["multi_gpu"]
-    assert mg["world_size_seen_by_backend"] == world and len(mg["per_rank_frames_per_s"]) == world
+    assert mg["world_size_seen_by_backend"] == world and len(mg["per_rank_frames_per_s"]) == world and mg["backend"] == "gloo"
     assert mg["min_rank_frames_per_s"] <= mg["max_rank_frames_per_s"] and mg["final_cloud_all_gather_ms"] > 0
     # value is the whole job over the slowest rank's time: never more than the sum of the ranks' own rates
     assert out["value"] <= sum(mg["per_rank_frames_per_s"]) * 1.001
+    assert out["verified"] is True and out["verified_timed_region"] is True, out.get("verification")
+    if workload == "sharded":
+        assert len(mg["per_rank_surfels"]) == world and min(mg["per_rank_surfels"]) > 0 and len(out["config"]["shards"]) == world
+
+
+_RCCL_WORKER = r"""
+import json, sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from densesurfelmapping_amd import replay
+dist = replay.init_collective("nccl", 1, 0, 0)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+out = {}
+for name, n in (("small", 1000), ("empty", 0), ("2GB", 48_000_000)):
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(n + 1)
+    cloud = torch.randint(0, 256, (n * 44,), dtype=torch.uint8, device="cuda:0", generator=g)
+    replay.merge_clouds(cloud)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    merged, counts = replay.merge_clouds(cloud)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert counts == [n] and merged.numel() == n * 44 and merged.is_cuda and torch.equal(merged, cloud)
+    out[name] = {"surfels": n, "bytes": n * 44, "ms": round(dt * 1e3, 3)}
+dist.destroy_process_group()
+print(json.dumps(out))
+"""
+
+
+def test_merge_clouds_through_rccl_on_one_gpu(tmp_path):
+    """The final merge of BASELINE configs[2] through RCCL itself (backend "nccl" of torch.distributed on ROCm), in a process
+    group of ONE on the test box's one GPU: the all-gather of the counts and of the padded cloud on DEVICE tensors -- a small
+    cloud, an empty one (every rank empty: nothing is gathered), and a 2 GB one.  Then the two drivers the way a user starts
+    them at --gpus 1: the replay CLI with --merge-at-world1, and bench.py, whose line names the backend that merged its clouds."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DSM_BENCH_ONE_DEVICE", "DSM_BENCH_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["2GB"]["bytes"] > 2_000_000_000 and rec["empty"]["surfels"] == 0
+    print("merge_clouds over RCCL, world 1:", rec)
+    r = subprocess.run([sys.executable, "-m", "densesurfelmapping_amd.replay", "--synthetic", "60", "--camera", "TINY", "--gpus", "1", "--merge-at-world1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    head = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert head["backend"] == "nccl" and head["merged_surfels"] == head["surfels"] > 0 and head["counts"] == [head["surfels"]]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--streams", "8", "--batches", "1",
+                        "--frames-per-step", "8", "--no-roofline", "--no-dropin", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    out = _bench_line(r)
+    mg = out["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["world_size_seen_by_backend"] == 1 and mg["final_cloud_all_gather_ms"] > 0, mg
+    assert mg["final_cloud_bytes_all_ranks"] == 44 * out["config"]["final_surfels_all_ranks"] > 0
+    assert out["verified"] is True and out["verified_timed_region"] is True
+
+
+def test_bench_sharded_workload_one_gpu():
+    """`bench.py --workload sharded` at --gpus 1: BASELINE configs[2]'s own path on one rank -- one subsequence streamed from
+    page-locked host memory through one handle -- with its final map checked against the CPU oracle's replay of the same 192
+    frames, the merge through RCCL (a group of one), a roofline and a CPU baseline in the line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DSM_BENCH_ONE_DEVICE", "DSM_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "sharded", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    out = _bench_line(r)
+    assert out["config"]["workload"].startswith("BASELINE configs[2]") and out["config"]["timed_frames_per_rank"] == 144
+    assert out["verified_timed_region"] is True and out["verification"]["equal"] is True and out["verification"]["surfels"] > 10000
+    assert out["multi_gpu"]["backend"] == "nccl" and out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
 
 
 def test_bench_refuses_more_gpus_than_visible():
