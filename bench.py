@@ -313,9 +313,10 @@ def pmc_8m(kernel, us):
 
 def event_timer(torch, ff):
     """HIP events on the handle's own stream (torch.cuda.Event only sees torch's current stream by default)."""
-    stream = torch.cuda.ExternalStream(ff.stream())
-
     def timed(fn, reps):
+        # fetched per measurement: dsm_stream is also the call that puts the handle's stream behind a batch it advanced with
+        # (include/dsm.h, ABI 4) -- a stream cached before batch calls would not be ordered behind them
+        stream = torch.cuda.ExternalStream(ff.stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):

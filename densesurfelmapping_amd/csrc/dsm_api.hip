@@ -17,7 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
-#include <unordered_set>
+#include <unordered_map>
 #include <vector>
 
 #include "dsm_device.h"
@@ -44,7 +44,8 @@ constexpr uint64_t kBatchBit = 1ull << 62;    // UpEntry::pending: a batch strea
 
 // the handles alive in this process: dsm_batch_destroy gives a handle back its freedom only if it still exists
 static std::mutex g_live_mu;
-static std::unordered_set<dsm_handle *> g_live;
+static std::unordered_map<dsm_handle *, uint64_t> g_live; // live handles -> their generation (an address can be handed out again)
+static uint64_t g_next_generation = 1;
 
 // A few host threads for the drop-in calls' bulk copies (frame rows into page-locked staging, the caller's surfel
 // array against / into / out of its page-locked shadow): one core moves ~15 GB/s, the copies of a 100 k-surfel map
@@ -130,6 +131,7 @@ class HostPool {
 };
 
 struct dsm_handle {
+    uint64_t generation = 0; // unique per dsm_create: a batch remembers it, so that a new handle at a destroyed handle's address is not taken for the old one
     dsm_config cfg;
     int device = 0;
     hipStream_t stream = nullptr; // the map stream: fuse + tail of every frame, in frame order; uploads; params
@@ -936,6 +938,10 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     // per-pipeline superpixel state
     int np = cfg->pipeline_depth > 0 ? cfg->pipeline_depth : 4;
     if (np != 1 && np != 2 && np != 4 && np != 8 && np != 12 && np != 16 && np != 24 && np != 32) { fail(h, DSM_E_INVALID, "pipeline_depth must be 1, 2, 4, 8, 12, 16, 24 or 32"); return bail(DSM_E_INVALID); }
+    if ((cfg->flags & DSM_FLAG_WAVE_STAMPS) && !kWaveStamps) {
+        fail(h, DSM_E_INVALID, "DSM_FLAG_WAVE_STAMPS: this library was built without phase stamps (-DDSM_WAVE_STAMPS=1: tools/wave_stamps.py builds such a copy)");
+        return bail(DSM_E_INVALID);
+    }
     h->n_pipe = np;
     if (np > 1) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
@@ -1001,7 +1007,8 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     (void)rc;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
-        g_live.insert(h);
+        h->generation = g_next_generation++;
+        g_live[h] = h->generation;
     }
     *out = h;
     return DSM_OK;
@@ -1447,15 +1454,27 @@ int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *imag
     const int w = h->hc.w, hh = h->hc.h, pitch = h->hc.pitch;
     if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
     if (n > 1 && (img_frame_step < img_step * (size_t)hh || depth_frame_step < depth_step * (size_t)hh)) return fail(h, DSM_E_INVALID, "frame step smaller than a frame");
-    int rc = bind_device(h);
-    if (rc) return rc;
+    // A handle that advances with a batch and whose own stream has carried nothing since the batch last ordered itself
+    // behind it (`touched` false: only batch calls since): whatever may still read these slots is covered by the batch's
+    // latest marker -- the upload stream waits for THAT, directly.  The handle's own stream is not involved: no wait and no
+    // marker on it now, and none for the batch's next call to come behind (those are barrier packets on hardware queues
+    // that other batches' graphs share: with 128 streamed subsequences, 256 of them per chunk).
+    const bool via_batch = h->batch_order_ev != nullptr && !h->touched;
+    if (via_batch) HIP_TRY(h, hipSetDevice(h->device));
+    else if (int rc = bind_device(h)) return rc;
     hipStream_t up = device_upload_stream(h->device, &h->up_which, h->batches_joined > 0); // (decided at the handle's first upload)
     if (!up) return fail(h, DSM_E_HIP, "no upload stream on device %d", h->device);
     // behind the frames that may still read these slots (dsm_handle::rd_ring): the newest dsm_replay_enqueue call that
     // reads one of them -- or, if frames were enqueued some other way since the last upload, behind everything enqueued so
     // far for this handle (its map stream runs fuse + tail of every frame after the superpixel stages that read the slots,
     // and waits for the batches the handle takes part in)
-    if (h->reads_untracked) {
+    if (via_batch) {
+        if (h->reads_untracked) {
+            HIP_TRY(h, hipStreamWaitEvent(up, h->batch_order_ev, 0));
+            h->reads_untracked = false;
+            h->rd_n = 0;
+        }
+    } else if (h->reads_untracked) {
         HIP_TRY(h, hipEventRecord(h->ev_fence, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(up, h->ev_fence, 0));
         h->reads_untracked = false;
@@ -1848,6 +1867,7 @@ hipStream_t batch_stream_take(int device) {
 
 struct dsm_batch {
     std::vector<dsm_handle *> hs;
+    std::vector<uint64_t> gens; // the handles' generations at dsm_batch_create
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false; // false: one of the device's reserved batch streams
@@ -1896,16 +1916,13 @@ int batch_rings_in_step(dsm_batch *b) {
 // are queued on -- a batch's next chunk could not start before whatever another batch had queued in front of those markers
 // had run.)  The batch stream is ordered behind a handle's own stream only when a per-handle call may have put work there
 // since the last time (dsm_handle::touched: uploads, a replay of its own, a map download ...).
-#ifndef DSM_BATCH_PARAMS_ON_BATCH
-#define DSM_BATCH_PARAMS_ON_BATCH 1
-#endif
 int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
                 const float *inv_poses16 = nullptr) {
     for (size_t j = 0; j < b->hs.size(); j++) {
         dsm_handle *h = b->hs[j];
         if (!h->map_valid) return bfail(b, DSM_E_STATE, "handle %zu has no resident map: call dsm_map_upload first (n may be 0)", j);
         const size_t o = j * (size_t)n_frames + (size_t)i0;
-        if (!DSM_BATCH_PARAMS_ON_BATCH || h->touched) {
+        if (h->touched) {
             BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
             BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
             h->touched = false;
@@ -1914,13 +1931,9 @@ int batch_stage(dsm_batch *b, int n_frames, int i0, int m, const int32_t *slots,
         if (h->batch_order_ev && h->batch_order_ev != b->ev_out) BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->batch_order_ev, 0));
         int staged = 0;
         const int rc = stage_params_batch(h, m, slots + o, ref_idx + o, poses16 + 16 * o, inv_poses16 ? inv_poses16 + 16 * o : nullptr, &staged,
-                                          DSM_BATCH_PARAMS_ON_BATCH ? b->stream : nullptr);
+                                          b->stream);
         if (rc) return bfail(b, rc, "handle %zu: %s", j, h->err.c_str());
         if (staged != m) return bfail(b, DSM_E_STATE, "handle %zu: parameter rings of the batch are out of step", j);
-        if (!DSM_BATCH_PARAMS_ON_BATCH) {
-            BHIP_TRY(b, hipEventRecord(h->ev_fence, h->stream));
-            BHIP_TRY(b, hipStreamWaitEvent(b->stream, h->ev_fence, 0));
-        }
         if (h->up_n) { // frames this handle was sent with dsm_frame(s)_upload_async: the uploads that wrote the slots these frames read
             int r_lo, r_hi;
             slot_range(slots + o, m, &r_lo, &r_hi);
@@ -1948,8 +1961,7 @@ int batch_map_grows(dsm_batch *b, int m) {
 int batch_advance(dsm_batch *b, int m) {
     BHIP_TRY(b, hipEventRecord(b->ev_out, b->stream));
     for (dsm_handle *h : b->hs) {
-        if (DSM_BATCH_PARAMS_ON_BATCH) h->batch_order_ev = b->ev_out; // (waited for when the handle's stream is next used)
-        else BHIP_TRY(b, hipStreamWaitEvent(h->stream, b->ev_out, 0));
+        h->batch_order_ev = b->ev_out; // (waited for when the handle's stream is next used)
         h->shadow_n = -1;
         h->reads_untracked = true;
         h->frames_submitted += m;
@@ -1981,6 +1993,7 @@ int dsm_batch_create(dsm_handle *const *handles, int32_t n, dsm_batch **out) {
     dsm_batch *b = new (std::nothrow) dsm_batch();
     if (!b) return bfail(nullptr, DSM_E_HIP, "out of host memory");
     b->hs.assign(handles, handles + n);
+    for (int j = 0; j < n; j++) b->gens.push_back(handles[j]->generation);
     for (dsm_handle *h : b->hs) h->batches_joined++;
     b->device = handles[0]->device;
     auto bail = [&](int code) {
@@ -2023,11 +2036,13 @@ void dsm_batch_destroy(dsm_batch *b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     { // the batch's copy of the handles' contexts goes with it (a handle destroyed before its batch is simply skipped)
         std::lock_guard<std::mutex> lk(g_live_mu);
-        for (dsm_handle *h : b->hs)
-            if (g_live.count(h)) {
-                if (h->batches_joined > 0) h->batches_joined--;
-                if (h->batch_order_ev == b->ev_out) h->batch_order_ev = nullptr; // (the batch has finished: nothing left to wait for)
-            }
+        for (size_t j = 0; j < b->hs.size(); j++) {
+            dsm_handle *h = b->hs[j];
+            const auto it = g_live.find(h);
+            if (it == g_live.end() || j >= b->gens.size() || it->second != b->gens[j]) continue; // destroyed (its address may belong to a newer handle by now)
+            if (h->batches_joined > 0) h->batches_joined--;
+            if (h->batch_order_ev == b->ev_out) h->batch_order_ev = nullptr; // (the batch has finished: nothing left to wait for)
+        }
     }
     if (b->graph) (void)hipGraphExecDestroy(b->graph);
     if (b->ev_out) (void)hipEventDestroy(b->ev_out);

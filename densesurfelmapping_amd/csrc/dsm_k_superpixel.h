@@ -207,7 +207,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     __shared__ float4 s_core[kTileCellsX * kTileCellsY];
     __shared__ double s_inv[kTileCellsX * kTileCellsY];
-    __shared__ float s_invf[kTileCellsX * kTileCellsY]; // the same rounded to float, for the filtered pick
+    __shared__ float s_s20[kTileCellsX * kTileCellsY]; // 20 x the same rounded to float (0 without a mean depth), for the filtered pick
     // the tile's pixels whose pick the fp32 filter leaves open (tile row << 6 | tile column), for the dense pass below
     __shared__ unsigned short s_open[kTileW * kTileH];
     __shared__ int s_n_open;
@@ -226,12 +226,14 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
             s_core[tid] = c->core[gy * gw + gx];
             const double inv = c->inv_depth[gy * gw + gx];
             s_inv[tid] = inv;
-            s_invf[tid] = (float)inv;
+            s_s20[tid] = seed_s20(s_core[tid].w, inv);
         }
     }
     __syncthreads();
-    // what becomes of a pixel once its pick is known (FF.cpp:442-451 and the stable-skip bookkeeping, see resolve_worklist)
-    auto settle = [&](int p, int l, int pick) {
+    // what becomes of a pixel once its pick is known (FF.cpp:442-451 and the stable-skip bookkeeping, see resolve_worklist).
+    // tl = tmin of the pixel's old seed (-1 never changes; >= 0 only moves among values >= 0: it may be read at any time),
+    // tp = tmin of the picked seed, read coherently after the pick was known.
+    auto settle = [&](int p, int l, int pick, int tl, int tp) {
         if (pick < 0) { // every candidate cost >= the reference's 1e6 sentinel: it would index seeds[-1]
             atomicOr(c->status, kStatusBadPick);
             if (FIRST) label_put(c->label, (unsigned)p, 0); else label_put(c->cand, (unsigned)p, l);
@@ -239,12 +241,11 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
             label_put(c->label, (unsigned)p, pick);
         } else {
             label_put(c->cand, (unsigned)p, pick);
-            const int tl = ld_off(c->tmin, (unsigned)l << 2); // -1 never changes; >= 0 only moves among values >= 0
             if (tl == -1) {
                 // the old seed was unstable at sweep start: this pixel is evaluated whatever happens
                 // elsewhere, so its pick loses `stable` no later than at p
-                if (load_coherent(&c->tmin[pick]) > p) atomicMin(&c->tmin[pick], p);
-            } else if (pick != l && c->tmin[pick] != -1) {
+                if (tp > p) atomicMin(&c->tmin[pick], p);
+            } else if (pick != l && tp != -1) {
                 // old and new seed both stable at sweep start: whether this pixel is evaluated depends
                 // on the scan order -- resolved below
                 const int slot = atomicAdd(c->work_count, 1);
@@ -252,11 +253,16 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
             }
         }
     };
+    auto tmin_of = [&](int s) { // tmin[s] by a 32-bit offset from the uniform base, coherently (other workgroups lower it)
+        return __hip_atomic_load(reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(c->tmin) + ((unsigned)s << 2)), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+    };
     const int x = bx + (tid & (kTileW - 1)), y0 = by + (tid / kTileW) * kColumn; // y0 is a multiple of 4: one quadrant row
     if (x < w && y0 < h) { // (no early return: every thread meets the barrier below)
-        // the column's pixels, one round trip
+        // the column's pixels, one round trip; the stable-skip state of their old seeds right behind them
         float pix_i[kColumn], pix_d[kColumn];
-        int lab[kColumn];
+        int lab[kColumn], tl[kColumn], pick[kColumn];
+        bool live[kColumn];
         const unsigned p0 = (unsigned)(__mul24(y0, pitch) + x);
 #pragma unroll
         for (int r = 0; r < kColumn; r++) {
@@ -265,31 +271,35 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
             pix_d[r] = ld_off(dep, p4);
             lab[r] = FIRST ? 0 : label_at(label_in, p);
         }
-        const PickQuad quad = pick_quad(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &inv_f) {
+        if (!FIRST) {
+#pragma unroll
+            for (int r = 0; r < kColumn; r++) tl[r] = ld_off(c->tmin, (unsigned)(lab[r] < 0 ? 0 : lab[r]) << 2);
+        }
+        const PickCol quad = pick_col(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &s20) {
             const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
             const float4 v = s_core[li];
             sx = v.x; sy = v.y; si = v.z; sd = v.w;
-            inv_f = s_invf[li];
+            s20 = s_s20[li];
         });
+        // ---- the four picks: the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast),
+        // straight-line for the whole column (rows beyond the image repeat row 0's pixel and are dropped below)
 #pragma unroll
         for (int r = 0; r < kColumn; r++) {
             const int y = y0 + r;
-            if (y >= h) break;
-            const int p = (int)p0 + r * pitch;
-            if (!has_candidate_cell(x, y, gw, gh)) {
-                // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
-                // every seed window ends before them, and k_apply_labels keeps a -1)
-                if (FIRST) label_put(c->label, (unsigned)p, -1);
-                continue;
-            }
-            // the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast).  A pixel it
-            // leaves open goes onto the tile's list: the reference's typed arithmetic is several hundred instructions, and
-            // run here it would run for the whole wave whenever ONE of its 64 pixels is open -- 16 % of the wave-rows on
-            // smooth synthetic depth, and most of them on the reference's own kind of input (kitti_publisher: depth = bf /
-            // quantised disparity, a few grey levels), where a tenth of the first sweep's pixels sit exactly between two
-            // seeds of equal intensity whose inverse depths lie on the disparity lattice.
-            const int pick = pick_seed_fast(quad, x, y, pix_i[r], pix_d[r], gw);
-            const bool open = pick == kPickUnsure;
+            live[r] = y < h && has_candidate_cell(x, y, gw, gh);
+            pick[r] = pick_seed_fast(quad, y, pix_i[r], pix_d[r], gw);
+            // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
+            // every seed window ends before them, and k_apply_labels keeps a -1)
+            if (FIRST && y < h && !live[r]) label_put(c->label, p0 + (unsigned)(r * pitch), -1);
+        }
+        // ---- a pixel the filter leaves open goes onto the tile's list: the reference's typed arithmetic is several hundred
+        // instructions, and run here it would run for the whole wave whenever ONE of its 64 pixels is open -- 16 % of the
+        // wave-rows on smooth synthetic depth, and most of them on the reference's own kind of input (kitti_publisher: depth
+        // = bf / quantised disparity, a few grey levels), where a tenth of the first sweep's pixels sit exactly between two
+        // seeds of equal intensity whose inverse depths lie on the disparity lattice.
+#pragma unroll
+        for (int r = 0; r < kColumn; r++) {
+            const bool open = live[r] && pick[r] == kPickUnsure;
             const unsigned long long m = __ballot(open);
             if (m) {
                 const int rk = rank_below(m);
@@ -298,8 +308,17 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
                 base = __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1);
                 if (open) s_open[base + rk] = (unsigned short)((((tid / kTileW) * kColumn + r) << 6) | (tid & (kTileW - 1)));
             }
-            if (!open) settle(p, lab[r], pick);
+            live[r] = live[r] && !open;
         }
+        // ---- the settled ones: the picked seeds' stable-skip state for the whole column in one round trip, then the stores
+        int tp[kColumn];
+        if (!FIRST) {
+#pragma unroll
+            for (int r = 0; r < kColumn; r++) tp[r] = tmin_of(pick[r] < 0 ? 0 : pick[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kColumn; r++)
+            if (live[r]) settle((int)p0 + r * pitch, lab[r], pick[r], FIRST ? 0 : tl[r], FIRST ? 0 : tp[r]);
     }
     __syncthreads();
     // ---- the open pixels of the tile, packed: 64 to a wave whatever rows and columns they came from
@@ -317,7 +336,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
             has_d = v.w > 0;
             inv_d = s_inv[li];
         });
-        settle((int)p, l, pick);
+        settle((int)p, l, pick, FIRST ? 0 : ld_off(c->tmin, (unsigned)l << 2), FIRST || pick < 0 ? 0 : tmin_of(pick));
     }
 }
 

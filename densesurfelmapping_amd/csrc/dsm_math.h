@@ -140,115 +140,191 @@ DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, Loa
 // lies strictly below all the others and below the 1e6 sentinel: then the reference's strict '<' scan picks the same
 // candidate whatever the order.  Otherwise it returns kPickUnsure and the caller runs pick_seed.
 //
-// Error bound (u = 2^-24; the double roundings of the reference are 2^-29 of that and ignored in the slack).  All three
-// cost terms are >= 0, so sums do not cancel.  Spatial term: the same fp32 operations in both forms except the last
-// add (dist / 16 is an exact scaling): <= 2u relative.  Intensity term: the reference rounds di^2 / 100 to double, adds in
-// double and rounds once to float; here di^2 * RN(0.01) and the add: <= 4u of the sum.  Depth term, D = 1 / mean_depth:
-// the reference forms dd = RN32(D - p) from the double D, here from Df = RN32(D): |dd~ - dd| <= e = u (|Df| + 3 |dd~|);
-// squaring and scaling by 400: |T~ - T| <= 400 e (2 |dd~| + e) + 4u T~; the final add 2u.  In all
-//     |cost~ - cost| <= 10u cost~ + 400 e (2 |dd~| + e),
-// used below with 16u and 800, which also covers the roundings of the bound's own evaluation.
-// tests/hostemu.cpp checks the bound against the reference costs on every candidate of its test frames.
+// Round 6: the filter is laid out for PACKED fp32 -- gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for a whole
+// wave in the slot of their scalar forms, so the four candidates of a pixel are two register pairs -- with every factor
+// that does not depend on the pixel folded into the candidate once per column of four pixels, and the pixel's inverse
+// depth from v_rcp_f32 (1 ulp; the reference's correctly rounded quotient costs ten more instructions) with its error
+// inside the bound.  Per candidate (xf, yq = y / 4, pi, p20 = 20 * rcp(depth) are the pixel's):
+//     ax16   = RN(RN(sx - xf)^2) / 16                     once per column
+//     dist16 = fma(sy/4 - yq, sy/4 - yq, ax16)            = RN((sy - y)^2 + RN((sx - x)^2)) / 16
+//     t      = RN(RN(si - pi) * 0.1f),  c_no = fma(t, t, dist16)
+//     dd20   = fma(s20, m, m ? -p20 : 0)                 s20 = RN32(20 / mean_depth) (0 without one), m = 1 (0: no depth term)
+//     c      = fma(dd20, dd20, c_no)
+//
+// Error bound (u = 2^-24; the double roundings of the reference are 2^-29 of that and ignored).  All three cost terms are
+// >= 0, so sums do not cancel.  Spatial term: the reference rounds (sy - y)^2 before the add, here it is exact inside the
+// FMA: <= 3u relative.  Intensity term: the reference's RN32(di^2) / 100 against t^2 = 0.01 di^2 (1 + <=u)^4: <= 5u.  The
+// two final roundings: <= 2u.  So |c_no~ - c_no| <= 8u c_no~.  Depth term, exact value 400 dd^2 with dd = RN32(D - p),
+// D = 1.0 / mean_depth (double), p = RN32(1 / depth): s20 differs from 20 D by u |s20|; the pixel side from 20 p by
+// 20 |rcp - p| + u |p20| <= 4u |p20| + 20 * 2^-126 (v_rcp_f32 is within one ulp of the correctly rounded quotient --
+// tests/test_gpu_parity.py walks every float -- and flushes a denormal quotient to 0); the subtraction and the reference's own
+// rounding of dd one u |dd20| each; |p20| <= |s20| + |dd20|:
+//     |dd20~ - 20 dd| <= e20 = u (5 |s20| + 6.1 |dd20~|) + 2.4e-37,   |dd20~^2 - 400 dd^2| <= e20 (2 |dd20~| + e20),
+// the reference's RN32(dd^2) and the last add 2u more.  In all
+//     |c~ - cost| <= 11u c~ + e20 (2 |dd20~| + e20),
+// used below with 20u (4u of it for the candidate tag in the key's low bits) and e2 = 2 e20 in both factors, evaluated with
+// e2 = u (12 |s20| + 16 |dd20|) + 2e-36: that also covers the roundings of the bound's own evaluation.
+// tests/hostemu.cpp checks the bound against the reference costs on every candidate of its test frames, with the pixel's
+// inverse depth moved off the correctly rounded one by a hash-chosen ulp either way.
 constexpr int kPickUnsure = -2;
 struct FastCost {
     float c, err;
 };
 constexpr float kFastU = 5.9604645e-8f; // u = 2^-24
-// the depth term's share of the bound, 800 e (2 |dd| + e) with e = u (|Df| + 3 |dd|), rounded up to e800 (2 |dd| + e800),
-// e800 = 800 e: one operation less.  df800 = 800 u |Df|.  Monotone in both arguments (every operand is >= 0 and rounding is
-// monotone): evaluated at the largest |dd| and the largest |Df| of several candidates it bounds every one of them.
-DSM_HD float fast_cost_slack(float ad, float df800) {
-    const float e800 = __builtin_fmaf(2400.0f * kFastU, ad, df800);
-    return e800 * __builtin_fmaf(2.0f, ad, e800);
+
+// ---- two floats per operation.  Device: a register pair and one packed instruction; host (tests/hostemu.cpp): the same
+// IEEE operations component by component -- identical bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DSM_HD f32x2 f2_make(float a, float b) { f32x2 r; r.x = a; r.y = b; return r; }
+DSM_HD f32x2 f2_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DSM_HD f32x2 f2_mul(f32x2 a, f32x2 b) { return a * b; }
+DSM_HD f32x2 f2_sub(f32x2 a, f32x2 b) { return a - b; }
+// 1 / d by the hardware's reciprocal: within one ulp of the correctly rounded quotient, denormal quotients flushed to 0
+DSM_HD float rcp_1ulp(float d) { return __builtin_amdgcn_rcpf(d); }
+#else
+struct f32x2 {
+    float x, y;
+};
+DSM_HD f32x2 f2_make(float a, float b) { return f32x2{a, b}; }
+DSM_HD f32x2 f2_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+DSM_HD f32x2 f2_mul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+DSM_HD f32x2 f2_sub(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+// the host's stand-in for v_rcp_f32: the correctly rounded quotient moved by one ulp up, down or not at all (a hash of the
+// operand decides), denormal quotients flushed -- every value the hardware may return lies within this model's reach
+DSM_HD float rcp_1ulp(float d) {
+    const float q = 1.0f / d;
+    uint32_t b = __builtin_bit_cast(uint32_t, q);
+    if ((b & 0x7f800000u) == 0u) return 0.0f;
+    uint32_t hsh = __builtin_bit_cast(uint32_t, d) * 2654435761u;
+    hsh ^= hsh >> 15;
+    const uint32_t k = hsh % 3u;
+    if (q == q && (b & 0x7f800000u) != 0x7f800000u) b += k == 1u ? 1u : (k == 2u ? 0xffffffffu : 0u);
+    return __builtin_bit_cast(float, b);
+}
+#endif
+DSM_HD f32x2 f2_splat(float a) { return f2_make(a, a); }
+
+// the pixel side of the depth term: has = the reference's `inv_d > 0` (FF.cpp:404-405,378: depth > 0.01 and a quotient that
+// does not round to 0, i.e. a finite depth), p20 = 20 / depth for the filter
+DSM_HD bool pixel_has_inv_depth(float d) { return d > flt_below(0.01) && d < __builtin_inff(); }
+DSM_HD float pixel_p20(float d) { return 20.0f * rcp_1ulp(d); }
+// the seed side: 20 / mean_depth rounded once to float; 0 for a seed without a mean depth (its candidates never take the depth
+// term: PickCol::depth_ok) so that no infinity enters the arithmetic of a pixel that does not use it
+DSM_HD float seed_s20(float mean_depth, double inv_depth) { return mean_depth > 0 ? (float)(20.0 * inv_depth) : 0.0f; }
+
+// the depth term's share of the bound: e2 (2 |dd20| + e2), e2 = 16u |dd20| + df, df = 12u max |s20| + 2e-36.  Monotone in both
+// arguments (every operand is >= 0 and rounding is monotone): evaluated at the largest |dd20| and the largest |s20| of several
+// candidates it bounds every one of them.
+DSM_HD float fast_cost_df(float s20_abs_max) { return __builtin_fmaf(12.0f * kFastU, s20_abs_max, 2e-36f); }
+DSM_HD float fast_cost_slack(float ad20, float df) {
+    const float e2 = __builtin_fmaf(16.0f * kFastU, ad20, df);
+    return e2 * __builtin_fmaf(2.0f, ad20, e2);
 }
 // bound on |cost~ - cost| (20u: 4u of it for the candidate tag of pick_seed_fast); monotone in c and in the slack
 DSM_HD float fast_cost_err(float c, float slack) { return __builtin_fmaf(20.0f * kFastU, c, slack); }
-// the cost itself; ad = |dd| of the depth term (whether or not it applies)
-DSM_HD float pixel_cost_fast_value(float sx, float sy, float si, float seed_inv_f, bool with_depth, float pix_i, float pix_invd, int x, int y, float &ad) {
-    const float ddx = sx - (float)x, ddy = sy - (float)y;
-    const float dist = __builtin_fmaf(ddy, ddy, ddx * ddx);
-    const float di = si - pix_i;
-    const float c_no = __builtin_fmaf(dist, 0.0625f, (di * di) * 0.01f);
-    // (no branches: every lane of a wave is another pixel, and the selects cost less than the exec-mask bookkeeping)
-    const float dd = seed_inv_f - pix_invd;
-    ad = fabsf(dd);
-    const float c_with = __builtin_fmaf(dd * dd, 400.0f, c_no);
-    return with_depth ? c_with : c_no;
-}
-// one candidate with its own bound: what the proof above is about, and what tests/hostemu.cpp checks against the
-// reference's costs on every candidate
-DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float seed_inv_f, bool with_depth, float pix_i, float pix_invd, int x, int y) {
+
+// one candidate with its own bound, in the filter's own operations: what the proof above is about, and what
+// tests/hostemu.cpp checks against the reference's costs on every candidate.  p20 = pixel_p20(depth).
+DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float s20, bool with_depth, float pix_i, float p20, int x, int y) {
+    const float ddx = sx - (float)x;
+    const float ax16 = (ddx * ddx) * 0.0625f;
+    const float ddyq = sy * 0.25f - (float)y * 0.25f;
+    const float dist16 = __builtin_fmaf(ddyq, ddyq, ax16);
+    const float t = (si - pix_i) * 0.1f;
+    const float c_no = __builtin_fmaf(t, t, dist16);
+    const float dd20 = __builtin_fmaf(s20, with_depth ? 1.0f : 0.0f, with_depth ? -p20 : 0.0f);
     FastCost r;
-    float ad;
-    r.c = pixel_cost_fast_value(sx, sy, si, seed_inv_f, with_depth, pix_i, pix_invd, x, y, ad);
-    r.err = fast_cost_err(r.c, with_depth ? fast_cost_slack(ad, (800.0f * kFastU) * fabsf(seed_inv_f)) : 0.0f);
+    r.c = __builtin_fmaf(dd20, dd20, c_no);
+    r.err = fast_cost_err(r.c, fast_cost_slack(fabsf(dd20), fast_cost_df(fabsf(s20))));
     return r;
 }
-// The candidates of a pixel are those of its 4 x 4 quadrant of a cell (see pick_seed): PickQuad holds them for all pixels
-// (x, y') with y' / 4 == y / 4, so that a thread working down a column of four pixels fetches them once.
-// load(gx, gy, sx, sy, si, seed_depth, inv_depth_f) fetches the cost-side state of grid cell (gx,gy) -- called for cells
-// clamped into the grid, so it needs no bounds of its own -- with the inverse mean depth rounded to float.
-struct PickQuad {
-    float sx[4], sy[4], si[4], sd[4], sinv[4]; // candidate k = (x offset k >> 1, y offset k & 1), the reference's scan order
-    bool col_ok[2], row_in[2];                  // in the grid and, for columns, past the distance filter
-    bool depth_ok[2];                           // [row offset]: both candidates of that row either out of play or with a mean depth
-    float df800_max;                            // 800 u max |sinv|, for the bound the four candidates share (fast_cost_slack)
-    int gx0, gy0;
+
+// The candidates of a pixel are those of its 4 x 4 quadrant of a cell (see pick_seed), and a thread works down a column of
+// four pixels: PickCol holds, for the column x and all rows y' with y' / 4 == y / 4, the four candidates (k = (x offset
+// k >> 1, y offset k & 1), the reference's scan order) as two pairs -- (0, 1) and (2, 3) -- with everything folded in that
+// does not depend on the row.  load(gx, gy, sx, sy, si, seed_depth, s20) fetches the cost-side state of grid cell (gx, gy) --
+// called for cells clamped into the grid, so it needs no bounds of its own; s20 = seed_s20(...).
+struct PickCol {
+    f32x2 ax16[2], sy4[2], si[2], s20[2];
+    uint32_t floor_in[4];   // key floors of a row off the distance filter's edge: 0 for a candidate in play, else a sentinel above every cost
+    uint32_t floor_edge[4]; // ... of a row with y mod 8 == 4, where the upper neighbour row is out of play (FF.cpp:420-422)
+    bool depth_ok[2];       // [row offset]: both candidates of that row either out of play or with a mean depth
+    float df;               // fast_cost_df over the four candidates
+    int base;               // seed index of candidate 0
 };
-template <typename LoadSeedF> DSM_HD PickQuad pick_quad(int x, int y, int gw, int gh, LoadSeedF load) {
-    PickQuad q;
+constexpr uint32_t kKeySentinel = 0x7f7ffffcu; // the largest finite float with its two tag bits cleared
+template <typename LoadSeedF> DSM_HD PickCol pick_col(int x, int y, int gw, int gh, LoadSeedF load) {
+    PickCol q;
     const int bx = x / kCell, by = y / kCell;
     const int xr = x % kCell, yr = y % kCell;
-    q.gx0 = bx - (xr < kCell / 2 ? 1 : 0);
-    q.gy0 = by - (yr < kCell / 2 ? 1 : 0);
-    q.col_ok[0] = q.gx0 >= 0 && q.gx0 < gw;
-    q.col_ok[1] = q.gx0 + 1 >= 0 && q.gx0 + 1 < gw && xr != kCell / 2;
-    q.row_in[0] = q.gy0 >= 0 && q.gy0 < gh;
-    q.row_in[1] = q.gy0 + 1 >= 0 && q.gy0 + 1 < gh;
+    const int gx0 = bx - (xr < kCell / 2 ? 1 : 0), gy0 = by - (yr < kCell / 2 ? 1 : 0);
+    q.base = gy0 * gw + gx0;
+    const bool col_ok[2] = {gx0 >= 0 && gx0 < gw, gx0 + 1 >= 0 && gx0 + 1 < gw && xr != kCell / 2};
+    const bool row_in[2] = {gy0 >= 0 && gy0 < gh, gy0 + 1 >= 0 && gy0 + 1 < gh};
+    float sx[4], sy[4], si[4], sd[4], s20[4];
     for (int k = 0; k < 4; k++) {
-        int gx = q.gx0 + (k >> 1), gy = q.gy0 + (k & 1);
+        int gx = gx0 + (k >> 1), gy = gy0 + (k & 1);
         gx = gx < 0 ? 0 : (gx > gw - 1 ? gw - 1 : gx);
         gy = gy < 0 ? 0 : (gy > gh - 1 ? gh - 1 : gy);
-        load(gx, gy, q.sx[k], q.sy[k], q.si[k], q.sd[k], q.sinv[k]);
+        load(gx, gy, sx[k], sy[k], si[k], sd[k], s20[k]);
+        const bool in = col_ok[k >> 1] && row_in[k & 1];
+        q.floor_in[k] = in ? 0u : kKeySentinel + (uint32_t)k;
+        q.floor_edge[k] = (in && (k & 1) == 0) ? 0u : kKeySentinel + (uint32_t)k;
     }
-    q.df800_max = (800.0f * kFastU) * fmaxf(fmaxf(fabsf(q.sinv[0]), fabsf(q.sinv[1])), fmaxf(fabsf(q.sinv[2]), fabsf(q.sinv[3])));
+    const f32x2 xf = f2_splat((float)x);
+    for (int j = 0; j < 2; j++) {
+        const f32x2 ddx = f2_sub(f2_make(sx[2 * j], sx[2 * j + 1]), xf);
+        q.ax16[j] = f2_mul(f2_mul(ddx, ddx), f2_splat(0.0625f));
+        q.sy4[j] = f2_mul(f2_make(sy[2 * j], sy[2 * j + 1]), f2_splat(0.25f));
+        q.si[j] = f2_make(si[2 * j], si[2 * j + 1]);
+        q.s20[j] = f2_make(s20[2 * j], s20[2 * j + 1]);
+    }
+    q.df = fast_cost_df(fmaxf(fmaxf(fabsf(s20[0]), fabsf(s20[1])), fmaxf(fabsf(s20[2]), fabsf(s20[3]))));
     for (int j = 0; j < 2; j++)
-        q.depth_ok[j] = !q.row_in[j] | ((!q.col_ok[0] | (q.sd[j] > 0)) & (!q.col_ok[1] | (q.sd[2 + j] > 0))); // (no short cuts: lane masks)
+        q.depth_ok[j] = !row_in[j] | ((!col_ok[0] | (sd[j] > 0)) & (!col_ok[1] | (sd[2 + j] > 0))); // (no short cuts: lane masks)
     return q;
 }
 struct FastPickTrace { // what a host-side check wants to see of a pick (tests/hostemu.cpp); the kernels pass none
     float err;
     bool all_depth;
 };
-DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pix_d, int gw, FastPickTrace *trace = nullptr) {
-    const float invd = pixel_inv_depth(pix_d);
-    const bool row_ok[2] = {q.row_in[0], q.row_in[1] && y % kCell != kCell / 2};
-    bool live[4];
-    for (int k = 0; k < 4; k++) live[k] = q.col_ok[k >> 1] && row_ok[k & 1];
+DSM_HD int pick_seed_fast(const PickCol &q, int y, float pix_i, float pix_d, int gw, FastPickTrace *trace = nullptr) {
+    const bool edge = y % kCell == kCell / 2;
     // every live candidate has a mean depth (and the pixel a depth): per row offset that is known for the whole quadrant
     // (depth_ok); the upper row is out of play altogether for a pixel on the filter's edge
-    const bool all_depth = invd > 0 && q.depth_ok[0] && (q.depth_ok[1] || y % kCell == kCell / 2);
-    // FF.cpp:442-451: with every candidate's depth term applied the pick is the argmin with it, else the argmin without.
+    const bool all_depth = pixel_has_inv_depth(pix_d) && q.depth_ok[0] && (q.depth_ok[1] || edge);
+    // FF.cpp:442-451: with every candidate's depth term applied the pick is the argmin with it, else the argmin without
+    // (m = 0 switches the term off: s20 * 0 - 0 = 0, every s20 being finite or the cost infinite and the pick open; the
+    // pixel's side by a select, 20 / depth being anything at all for a pixel without a depth).
+    const f32x2 mm = f2_splat(all_depth ? 1.0f : 0.0f), p20m = f2_splat(all_depth ? -pixel_p20(pix_d) : 0.0f);
+    const f32x2 yq = f2_splat((float)y * 0.25f), pi = f2_splat(pix_i), tenth = f2_splat(0.1f);
+    f32x2 c[2], dd20[2];
+    for (int j = 0; j < 2; j++) {
+        const f32x2 ddyq = f2_sub(q.sy4[j], yq);
+        const f32x2 dist16 = f2_fma(ddyq, ddyq, q.ax16[j]);
+        const f32x2 t = f2_mul(f2_sub(q.si[j], pi), tenth);
+        const f32x2 c_no = f2_fma(t, t, dist16);
+        dd20[j] = f2_fma(q.s20[j], mm, p20m);
+        c[j] = f2_fma(dd20[j], dd20[j], c_no);
+    }
     // Costs are >= 0, so their bit patterns order like the values; the candidate's position in the reference's scan goes
     // into the two lowest bits (a change of < 4 ulp, inside the error bound): the smallest tagged cost names the winner.
-    // It is the reference's pick for sure if even the largest error bound of the four separates it from the runner-up
+    // A candidate out of play is lifted to a sentinel above every cost (its floor); a NaN cost has a bit pattern above the
+    // sentinels and never wins either, as it never wins the reference's '<'.  The pick is the reference's for sure if the
+    // ONE bound of the four -- the per-candidate bound (pixel_cost_fast) is monotone in the cost, in |dd20| and in |s20|, so
+    // at the largest of each it holds for every candidate, of a masked one too -- separates the winner from the runner-up
     // and from the sentinel the scan starts from.
-    // ONE bound for the four: the per-candidate bound (pixel_cost_fast) is monotone in the cost, in |dd| and in |Df|, so at
-    // the largest of each it holds for every candidate -- of a masked one too (its cell was clamped to a real one; the bound
-    // is merely larger).  The comparison below always used the largest of the four bounds; formed this way it costs 8
-    // instructions instead of 26 per pixel.
+    const float ck[4] = {c[0].x, c[0].y, c[1].x, c[1].y};
+    const float c_max = fmaxf(fmaxf(ck[0], ck[1]), fmaxf(ck[2], ck[3])); // (a NaN cost drops out of the maximum)
+    const float ad_max = fmaxf(fmaxf(fabsf(dd20[0].x), fabsf(dd20[0].y)), fmaxf(fabsf(dd20[1].x), fabsf(dd20[1].y)));
     uint32_t key[4];
-    float c_max = 0.0f, ad_max = 0.0f;
     for (int k = 0; k < 4; k++) {
-        float ad;
-        const float ck = pixel_cost_fast_value(q.sx[k], q.sy[k], q.si[k], q.sinv[k], all_depth, pix_i, invd, x, y, ad);
-        c_max = fmaxf(c_max, ck); // (a NaN cost drops out of the maximum and, below, out of the candidates: it never wins the reference's '<' either)
-        ad_max = fmaxf(ad_max, ad);
-        const uint32_t bits = __builtin_bit_cast(uint32_t, ck);
-        // a cell outside the grid or past the distance filter never wins; neither does a NaN or negative (sign-bit) cost
-        key[k] = (live[k] && ck >= 0.0f) ? ((bits & ~3u) | (uint32_t)k) : 0x7f7ffffcu + (uint32_t)k;
+        const uint32_t tagged = (__builtin_bit_cast(uint32_t, ck[k]) & ~3u) | (uint32_t)k;
+        const uint32_t fl = edge ? q.floor_edge[k] : q.floor_in[k];
+        key[k] = tagged > fl ? tagged : fl;
     }
-    const float err_max = fast_cost_err(c_max, all_depth ? fast_cost_slack(ad_max, q.df800_max) : 0.0f);
+    const float err_max = fast_cost_err(c_max, fast_cost_slack(ad_max, q.df));
     if (trace) { trace->err = err_max; trace->all_depth = all_depth; }
     const uint32_t lo01 = key[0] < key[1] ? key[0] : key[1], hi01 = key[0] < key[1] ? key[1] : key[0];
     const uint32_t lo23 = key[2] < key[3] ? key[2] : key[3], hi23 = key[2] < key[3] ? key[3] : key[2];
@@ -256,13 +332,12 @@ DSM_HD int pick_seed_fast(const PickQuad &q, int x, int y, float pix_i, float pi
     const uint32_t mid_a = lo01 < lo23 ? lo23 : lo01, mid_b = hi01 < hi23 ? hi01 : hi23;
     const uint32_t second = mid_a < mid_b ? mid_a : mid_b;
     const float c1 = __builtin_bit_cast(float, first), c2 = __builtin_bit_cast(float, second);
-    const int k = (int)(first & 3u);
-    if (c1 + err_max < c2 - err_max && c1 + err_max < 1e6f) return (q.gy0 + (k & 1)) * gw + (q.gx0 + (k >> 1));
+    if (c1 + err_max < c2 - err_max && c1 + err_max < 1e6f) return q.base + (int)(first & 1u) * gw + (int)((first >> 1) & 1u);
     return kPickUnsure;
 }
 template <typename LoadSeedF>
 DSM_HD int pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeedF load, FastPickTrace *trace = nullptr) {
-    return pick_seed_fast(pick_quad(x, y, gw, gh, load), x, y, pix_i, pix_d, gw, trace);
+    return pick_seed_fast(pick_col(x, y, gw, gh, load), y, pix_i, pix_d, gw, trace);
 }
 
 // ------------------------------------------------- robust mean depth of a seed, FF.cpp:530-556

@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 3 /* 3: the *_inv entry points (the caller's own pose inverse) */
+#define DSM_ABI_VERSION 4 /* 3: the *_inv entry points (the caller's own pose inverse).  4: a batch no longer touches its handles'
+                             streams at every call -- a handle's stream comes behind its batch at the handle's NEXT dsm_* call
+                             (dsm_stream's note): a caller that cached the hipStream_t must fetch it again after batch calls;
+                             dsm_create refuses DSM_FLAG_WAVE_STAMPS in a library built without stamp code; dsm_debug_tier_counts */
 
 typedef enum {
     DSM_OK = 0,
@@ -108,7 +111,8 @@ typedef struct dsm_config {
 
 #define DSM_FLAG_WAVE_STAMPS 4u /* debug: allocate the per-wave phase-stamp buffer read by dsm_debug_wave_stamps -- in a library
                                    built with -DDSM_WAVE_STAMPS=1 (tools/wave_stamps.py); the shipped build has no stamp code in
-                                   its kernels, ignores the flag, and dsm_debug_wave_stamps reports DSM_E_STATE */
+                                   its kernels and dsm_create REFUSES the flag (DSM_E_INVALID): a profiling run on the wrong
+                                   library fails at once instead of reading an empty buffer later */
 
 typedef struct dsm_handle dsm_handle;
 

@@ -96,11 +96,12 @@ void assign(Emu &e, bool first) {
                                     });
         // the kernel's filtered pick (dsm_math.h, pick_seed_fast): wherever it answers, it must be the reference's pick
         FastPickTrace trace = {0.0f, false};
+        const float p20 = pixel_has_inv_depth(e.D(x, y)) ? pixel_p20(e.D(x, y)) : 0.0f; // (the host's model of v_rcp_f32: a hash-chosen ulp off)
         const int fast = pick_seed_fast(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
-                                        [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &invf) {
+                                        [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &s20) {
                                             const int s = gy * e.gw + gx;
                                             sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i;
-                                            sd = e.core[s].d; invf = (float)e.inv_depth[s];
+                                            sd = e.core[s].d; s20 = seed_s20(sd, e.inv_depth[s]);
                                             const bool hd = sd > 0;
                                             // ... and its error bound must hold against the reference's typed costs
                                             const float invd = pixel_inv_depth(e.D(x, y));
@@ -108,21 +109,23 @@ void assign(Emu &e, bool first) {
                                             const bool with = pixel_cost(sx, sy, si, hd, e.inv_depth[s], e.I(x, y), invd, x, y, cn, cd);
                                             for (int depth_term = 0; depth_term < 2; depth_term++) {
                                                 if (depth_term && !with) continue;
-                                                const FastCost f = pixel_cost_fast(sx, sy, si, invf, depth_term != 0, e.I(x, y), invd, x, y);
+                                                const FastCost f = pixel_cost_fast(sx, sy, si, s20, depth_term != 0, e.I(x, y), p20, x, y);
                                                 const double ref = depth_term ? (double)cd : (double)cn;
                                                 e.fast_checked++;
                                                 if (!(fabs((double)f.c - ref) <= (double)f.err)) e.fast_bound_violations++;
                                             }
                                         }, &trace);
         {
-            // the ONE bound the four candidates share must be at least every candidate's own (masked ones included)
-            const PickQuad q = pick_quad(x, y, e.gw, e.gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &invf) {
-                const int s = gy * e.gw + gx;
-                sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i; sd = e.core[s].d; invf = (float)e.inv_depth[s];
-            });
-            const float invd = pixel_inv_depth(e.D(x, y));
+            // the ONE bound the four candidates share must be at least every candidate's own (masked ones included: the cells
+            // pick_col clamps into the grid)
+            const int gx0 = x / kCell - (x % kCell < kCell / 2 ? 1 : 0), gy0 = y / kCell - (y % kCell < kCell / 2 ? 1 : 0);
             for (int k = 0; k < 4; k++) {
-                const FastCost f = pixel_cost_fast(q.sx[k], q.sy[k], q.si[k], q.sinv[k], trace.all_depth, e.I(x, y), invd, x, y);
+                int gx = gx0 + (k >> 1), gy = gy0 + (k & 1);
+                gx = gx < 0 ? 0 : (gx > e.gw - 1 ? e.gw - 1 : gx);
+                gy = gy < 0 ? 0 : (gy > e.gh - 1 ? e.gh - 1 : gy);
+                const int s = gy * e.gw + gx;
+                const FastCost f = pixel_cost_fast(e.core[s].x, e.core[s].y, e.core[s].i, seed_s20(e.core[s].d, e.inv_depth[s]), trace.all_depth,
+                                                   e.I(x, y), p20, x, y);
                 e.fast_checked++;
                 if (f.err == f.err && !(f.err <= trace.err)) e.fast_bound_violations++;
             }

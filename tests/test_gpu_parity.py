@@ -1080,7 +1080,7 @@ def test_async_uploads_between_frame_by_frame_and_chunked_enqueues(mods, depth):
 @pytest.mark.parametrize("depth,chunk", [(24, 16), (1, 5), (8, 24)])
 def test_replay_engine_streams_in_chunks(mods, depth, chunk):
     """replay.HipEngine.replay -- what a rank of the sharded replay runs on its shard: frames streamed from page-locked
-    memory chunk by chunk (upload of chunk k+1 beside the kernels of chunk k, two slot halves in turn), through frame groups
+    memory chunk by chunk (upload of chunk k+1 beside the kernels of chunk k, three groups of frame slots in turn), through frame groups
     -- over many chunks with a ragged last one, from a source whose frames are copied into the engine's page-locked blocks
     by the prefetch thread and from one that keeps them page-locked itself; a second replay on the same engine continues
     the sequence.  The map equals the oracle's for the same frames, byte for byte."""
@@ -1138,6 +1138,26 @@ def test_bench_ranks_on_one_gpu(world, workload):
     assert out["verified"] is True and out["verified_timed_region"] is True, out.get("verification")
     if workload == "sharded":
         assert len(mg["per_rank_surfels"]) == world and min(mg["per_rank_surfels"]) > 0 and len(out["config"]["shards"]) == world
+
+
+def test_hardware_reciprocal_is_within_one_ulp(tmp_path):
+    """k_assign's filtered pick takes 1 / depth from v_rcp_f32 and prices its error into the bound (dsm_math.h: within one ulp of
+    the correctly rounded quotient, a denormal quotient possibly flushed to 0 -- an absolute error below 2^-126).  Walked over
+    EVERY float depth the reference gives an inverse depth to ((double)d > 0.01, FF.cpp:404), +inf included, on this GPU."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "_build", "rcp_ulp")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        exe = str(tmp_path / "rcp_ulp")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "rcp_ulp.hip"), "-o", exe],
+                       check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    print("v_rcp_f32 against the correctly rounded quotient:", rec)
+    assert rec["floats"] > 1_000_000_000 and rec["max_ulp_normal"] <= 1, rec
+    assert rec["denormal_err_max_in_2^-149"] <= 1 << 23, rec  # (below 2^-126 whatever the hardware does with a denormal quotient)
 
 
 _RCCL_WORKER = r"""

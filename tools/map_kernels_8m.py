@@ -76,9 +76,9 @@ def warp_leg(n_want):
     del wm
     wp = np.eye(4, dtype=np.float32)
     wp[:3, 3] = (0.01, -0.02, 0.005)
-    stream = torch.cuda.ExternalStream(ff.stream())
     ff.map_warp(wp)
     ff.synchronize()
+    stream = torch.cuda.ExternalStream(ff.stream())  # (fetched right before use: include/dsm.h, dsm_stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(30):
