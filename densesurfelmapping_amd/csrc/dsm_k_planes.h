@@ -499,6 +499,18 @@ __device__ __forceinline__ double fit_ordered_sum(const float *xc, const float *
     return 2.0 * acc;
 }
 
+// x += x rotated within its row of sixteen lanes (DPP row_ror: CTRL = 0x120 + lanes), for a lane's quarter of a Jacobian sum
+// and the two values its exactness test needs
+template <int CTRL> __device__ __forceinline__ void quarter_fold(double &part, float &t_sum, uint32_t &t_min) {
+    const long long pb = __double_as_longlong(part);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)pb, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(pb >> 32), CTRL, 0xf, 0xf, false);
+    part += __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+    t_sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t_sum), CTRL, 0xf, 0xf, false));
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t_min, CTRL, 0xf, 0xf, false);
+    t_min = o < t_min ? o : t_min;
+}
+
 template <int TIER> struct FitShape {
     static constexpr int kStride = TIER == kFitSmall ? kFitSmallStride : kFitStride;
     static constexpr int kChunks = TIER == kFitSmall ? (kFitSmallCap + 63) / 64 : 4; // 64-element chunks a list can span
@@ -682,7 +694,6 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
                 }
             }
             wave_lds_sync();
-            const double acc = fit_ordered_sum(xc, yc, xs, ys, m8, noncore, is_j, hr);
             // The Hessian sums read nothing but the points and which elements are in the Huber core: while the class
             // masks of all four seeds stay what they were when H was last summed (from the second step on they are
             // normally all-core), H, its damped inverse and the determinant are bit for bit the same, and the
@@ -691,7 +702,46 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
 #pragma unroll
             for (int k = 0; k < 4; k++) same = same && noncore[k] == h_masks[k];
             const bool reuse_inverse = __ballot(!same) == 0;
-            if (gl >= 10 && gl < 14) SJ[gl - 10] = acc;
+            // ... and then only four of a seed's sixteen lanes have a sum to take.  Round 6: all sixteen take a QUARTER of one
+            // -- lane gl = component (gl & 3) of J, blocks of eight elements gl >> 2, + 4, + 8, ... -- wherever the order of a sum
+            // provably does not matter: every term is the reference's own fp32 product widened to double, and while the
+            // magnitudes of a sum's terms span less than 2^29 no addition of any order rounds (dsm_math.h, gn_sum_is_exact:
+            // 99.8 % of these steps; tests/hostemu.cpp).  A lane carries sum|t| and the smallest non-zero |t| beside its
+            // quarter; if every sum of all four seeds passes, J is the ordered J bit for bit -- else the ordered sums run.
+            bool have_j = false;
+            if (reuse_inverse && __ballot((noncore[0] | noncore[1] | noncore[2] | noncore[3]) != 0) == 0) {
+                const int a = gl & 3;
+                const float *rc = s_col[g][3], *pc = a == 3 ? s_ones : s_col[g][a];
+                const int ps = a == 3 ? 0 : 1;
+                double part = 0.0;
+                float t_sum = 0.0f;
+                uint32_t t_min = 0xffffffffu;
+                for (int b = (gl >> 2) * 8; b < m8; b += 32) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(rc + b), xb = *reinterpret_cast<const float4 *>(rc + b + 4);
+                    const float4 ya = *reinterpret_cast<const float4 *>(pc + b * ps), yb = *reinterpret_cast<const float4 *>(pc + b * ps + 4);
+                    const float t[8] = {xa.x * ya.x, xa.y * ya.y, xa.z * ya.z, xa.w * ya.w, xb.x * yb.x, xb.y * yb.y, xb.z * yb.z, xb.w * yb.w};
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        part += (double)t[q];
+                        t_sum += fabsf(t[q]);
+                        const uint32_t key = gn_min_key(t[q]);
+                        t_min = key < t_min ? key : t_min;
+                    }
+                }
+                // the four quarters of a component sit 4 lanes apart within the seed's row of sixteen: row_ror 8, then 4
+                // (every lane ends with the same bits: x + y == y + x)
+                quarter_fold<0x128>(part, t_sum, t_min);
+                quarter_fold<0x124>(part, t_sum, t_min);
+                if (__ballot(!gn_sum_is_exact(t_sum, gn_min_key_value(t_min))) == 0) {
+                    if (gl < 4) SJ[gl] = 2.0 * part;
+                    have_j = true;
+                }
+            }
+            double acc = 0.0;
+            if (!have_j) {
+                acc = fit_ordered_sum(xc, yc, xs, ys, m8, noncore, is_j, hr);
+                if (gl >= 10 && gl < 14) SJ[gl - 10] = acc;
+            }
             if (!reuse_inverse) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) h_masks[k] = noncore[k];

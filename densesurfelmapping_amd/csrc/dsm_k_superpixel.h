@@ -205,9 +205,15 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
-    __shared__ float4 s_core[kTileCellsX * kTileCellsY];
-    __shared__ double s_inv[kTileCellsX * kTileCellsY];
-    __shared__ float s_s20[kTileCellsX * kTileCellsY]; // 20 x the same rounded to float (0 without a mean depth), for the filtered pick
+    // The seeds a tile can pick from, cell (cx0 + i, cy0 + j) at index j * kTileCellsX + i.  A cell OUTSIDE the grid holds a
+    // copy of the nearest one inside: the filtered pick reads its four candidates at fixed offsets from its first one,
+    // wherever the tile lies (such a candidate is out of play, dsm_math.h pick_col); the typed pick asks for cells inside only.
+    constexpr int kCells = kTileCellsX * kTileCellsY;
+    __shared__ float4 s_core[kCells];
+    __shared__ double s_inv[kCells];
+    // ... and for the filtered pick as one array per field (a pair of candidates = one ds_read2_b32, straight into the register
+    // pair of a packed operation): x / 4, y / 4, mean intensity, 20 / mean depth rounded to float (0 without one), mean depth
+    __shared__ float s_f[5][kCells];
     // the tile's pixels whose pick the fp32 filter leaves open (tile row << 6 | tile column), for the dense pass below
     __shared__ unsigned short s_open[kTileW * kTileH];
     __shared__ int s_n_open;
@@ -220,14 +226,19 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     const int cx0 = bx / kCell - 1, cy0 = by / kCell - 1;
     const int tid = threadIdx.x;
     if (tid == 0) s_n_open = 0;
-    if (tid < kTileCellsX * kTileCellsY) {
-        const int gx = cx0 + tid % kTileCellsX, gy = cy0 + tid / kTileCellsX;
-        if (gx >= 0 && gx < gw && gy >= 0 && gy < gh) {
-            s_core[tid] = c->core[gy * gw + gx];
-            const double inv = c->inv_depth[gy * gw + gx];
-            s_inv[tid] = inv;
-            s_s20[tid] = seed_s20(s_core[tid].w, inv);
-        }
+    if (tid < kCells) {
+        int gx = cx0 + tid % kTileCellsX, gy = cy0 + tid / kTileCellsX;
+        gx = gx < 0 ? 0 : (gx > gw - 1 ? gw - 1 : gx);
+        gy = gy < 0 ? 0 : (gy > gh - 1 ? gh - 1 : gy);
+        const float4 v = c->core[gy * gw + gx];
+        const double inv = c->inv_depth[gy * gw + gx];
+        s_core[tid] = v;
+        s_inv[tid] = inv;
+        s_f[0][tid] = v.x * 0.25f;
+        s_f[1][tid] = v.y * 0.25f;
+        s_f[2][tid] = v.z;
+        s_f[3][tid] = seed_s20(v.w, inv);
+        s_f[4][tid] = v.w;
     }
     __syncthreads();
     // what becomes of a pixel once its pick is known (FF.cpp:442-451 and the stable-skip bookkeeping, see resolve_worklist).
@@ -261,25 +272,26 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
     if (x < w && y0 < h) { // (no early return: every thread meets the barrier below)
         // the column's pixels, one round trip; the stable-skip state of their old seeds right behind them
         float pix_i[kColumn], pix_d[kColumn];
-        int lab[kColumn], tl[kColumn], pick[kColumn];
-        bool live[kColumn];
+        int lab[kColumn], tl[kColumn], pick[kColumn]; // (lab: the label plane's 16 bits as they are -- kNoLabel equals no pick)
+        bool live[kColumn], sure[kColumn];
         const unsigned p0 = (unsigned)(__mul24(y0, pitch) + x);
 #pragma unroll
         for (int r = 0; r < kColumn; r++) {
             const unsigned p = y0 + r < h ? p0 + (unsigned)(r * pitch) : p0, p4 = p << 2; // byte offsets into the 4-byte planes, see ld_off
             pix_i[r] = (float)ld_off(img, p);
             pix_d[r] = ld_off(dep, p4);
-            lab[r] = FIRST ? 0 : label_at(label_in, p);
+            lab[r] = FIRST ? 0 : (int)ld_off(label_in, p << 1);
         }
         if (!FIRST) {
+            const unsigned s_last = (unsigned)c->n_seed - 1u; // (a pixel without a label is never settled: any seed's entry will do)
 #pragma unroll
-            for (int r = 0; r < kColumn; r++) tl[r] = ld_off(c->tmin, (unsigned)(lab[r] < 0 ? 0 : lab[r]) << 2);
+            for (int r = 0; r < kColumn; r++) tl[r] = ld_off(c->tmin, ((unsigned)lab[r] < s_last ? (unsigned)lab[r] : s_last) << 2);
         }
-        const PickCol quad = pick_col(x, y0, gw, gh, [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &s20) {
-            const int li = __mul24(gy - cy0, kTileCellsX) + (gx - cx0);
-            const float4 v = s_core[li];
-            sx = v.x; sy = v.y; si = v.z; sd = v.w;
-            s20 = s_s20[li];
+        // (candidate 0's cell is at most one cell left of / above the tile: inside the staged halo, as are the other three)
+        const int li0 = __mul24(((y0 >> 3) - ((y0 & 7) < 4 ? 1 : 0)) - cy0, kTileCellsX) + (((x >> 3) - ((x & 7) < 4 ? 1 : 0)) - cx0);
+        const PickCol quad = pick_col(x, y0, gw, gh, [&](int k, int, int, float &sx4, float &sy4, float &si, float &sd, float &s20) {
+            const int li = li0 + (k >> 1) + (k & 1) * kTileCellsX;
+            sx4 = s_f[0][li]; sy4 = s_f[1][li]; si = s_f[2][li]; s20 = s_f[3][li]; sd = s_f[4][li];
         });
         // ---- the four picks: the argmin from fp32 costs with error bounds where that is decisive (dsm_math.h, pick_seed_fast),
         // straight-line for the whole column (rows beyond the image repeat row 0's pixel and are dropped below)
@@ -287,7 +299,9 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         for (int r = 0; r < kColumn; r++) {
             const int y = y0 + r;
             live[r] = y < h && has_candidate_cell(x, y, gw, gh);
-            pick[r] = pick_seed_fast(quad, y, pix_i[r], pix_d[r], gw);
+            const FastPick fpk = pick_seed_fast(quad, y, pix_i[r], pix_d[r], gw);
+            pick[r] = fpk.seed;
+            sure[r] = fpk.sure;
             // ragged border beyond every cell's reach: label -1, once per frame (no later stage changes these pixels:
             // every seed window ends before them, and k_apply_labels keeps a -1)
             if (FIRST && y < h && !live[r]) label_put(c->label, p0 + (unsigned)(r * pitch), -1);
@@ -299,7 +313,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         // seeds of equal intensity whose inverse depths lie on the disparity lattice.
 #pragma unroll
         for (int r = 0; r < kColumn; r++) {
-            const bool open = live[r] && pick[r] == kPickUnsure;
+            const bool open = live[r] && !sure[r];
             const unsigned long long m = __ballot(open);
             if (m) {
                 const int rk = rank_below(m);
@@ -314,7 +328,7 @@ template <bool FIRST, bool BATCH, int COLS> __global__ __launch_bounds__(256) vo
         int tp[kColumn];
         if (!FIRST) {
 #pragma unroll
-            for (int r = 0; r < kColumn; r++) tp[r] = tmin_of(pick[r] < 0 ? 0 : pick[r]);
+            for (int r = 0; r < kColumn; r++) tp[r] = tmin_of(live[r] ? pick[r] : 0); // (a settled pick is a seed index)
         }
 #pragma unroll
         for (int r = 0; r < kColumn; r++)

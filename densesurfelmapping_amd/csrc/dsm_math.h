@@ -166,7 +166,6 @@ DSM_HD int pick_seed(int x, int y, float pix_i, float pix_d, int gw, int gh, Loa
 // e2 = u (12 |s20| + 16 |dd20|) + 2e-36: that also covers the roundings of the bound's own evaluation.
 // tests/hostemu.cpp checks the bound against the reference costs on every candidate of its test frames, with the pixel's
 // inverse depth moved off the correctly rounded one by a hash-chosen ulp either way.
-constexpr int kPickUnsure = -2;
 struct FastCost {
     float c, err;
 };
@@ -243,40 +242,39 @@ DSM_HD FastCost pixel_cost_fast(float sx, float sy, float si, float s20, bool wi
 // The candidates of a pixel are those of its 4 x 4 quadrant of a cell (see pick_seed), and a thread works down a column of
 // four pixels: PickCol holds, for the column x and all rows y' with y' / 4 == y / 4, the four candidates (k = (x offset
 // k >> 1, y offset k & 1), the reference's scan order) as two pairs -- (0, 1) and (2, 3) -- with everything folded in that
-// does not depend on the row.  load(gx, gy, sx, sy, si, seed_depth, s20) fetches the cost-side state of grid cell (gx, gy) --
-// called for cells clamped into the grid, so it needs no bounds of its own; s20 = seed_s20(...).
+// does not depend on the row.  load(k, gx, gy, sx4, sy4, si, seed_depth, s20) fetches the cost-side state of grid cell
+// (gx, gy) -- which may lie OUTSIDE the grid by one cell: the loader then returns the state of the nearest cell inside (the
+// kernel's LDS tile keeps such copies in its halo; the candidate is out of play and only has to be finite-or-harmless) --
+// as sx / 4, sy / 4 (exact scalings), the mean intensity, the mean depth and s20 = seed_s20(...).
+// A candidate out of play (outside the grid, or past the reference's distance filter |8g + 4 - x| < 8) carries a penalty of
+// 1e30 in its spatial term: it sorts behind every real cost, and below only a pick under the reference's 1e6 sentinel counts.
 struct PickCol {
-    f32x2 ax16[2], sy4[2], si[2], s20[2];
-    uint32_t floor_in[4];   // key floors of a row off the distance filter's edge: 0 for a candidate in play, else a sentinel above every cost
-    uint32_t floor_edge[4]; // ... of a row with y mod 8 == 4, where the upper neighbour row is out of play (FF.cpp:420-422)
-    bool depth_ok[2];       // [row offset]: both candidates of that row either out of play or with a mean depth
-    float df;               // fast_cost_df over the four candidates
-    int base;               // seed index of candidate 0
+    f32x2 ax16[2];      // (sx - x)^2 / 16 (+ penalty)
+    f32x2 ax16_edge[2]; // the same for a row with y mod 8 == 4, where the upper neighbour row is out of play too (FF.cpp:420-422)
+    f32x2 sy4[2], si[2], s20[2];
+    bool depth_ok[2]; // [row offset]: both candidates of that row either out of play or with a mean depth
+    float df;         // fast_cost_df over the four candidates
+    int base;         // seed index of candidate 0
 };
-constexpr uint32_t kKeySentinel = 0x7f7ffffcu; // the largest finite float with its two tag bits cleared
+constexpr float kPickPenalty = 1e30f;
 template <typename LoadSeedF> DSM_HD PickCol pick_col(int x, int y, int gw, int gh, LoadSeedF load) {
     PickCol q;
-    const int bx = x / kCell, by = y / kCell;
-    const int xr = x % kCell, yr = y % kCell;
-    const int gx0 = bx - (xr < kCell / 2 ? 1 : 0), gy0 = by - (yr < kCell / 2 ? 1 : 0);
+    const int xr = x & (kCell - 1), yr = y & (kCell - 1); // (x, y >= 0)
+    const int gx0 = (x >> 3) - (xr < kCell / 2 ? 1 : 0), gy0 = (y >> 3) - (yr < kCell / 2 ? 1 : 0);
+    static_assert(kCell == 8, "the shifts above");
     q.base = gy0 * gw + gx0;
-    const bool col_ok[2] = {gx0 >= 0 && gx0 < gw, gx0 + 1 >= 0 && gx0 + 1 < gw && xr != kCell / 2};
-    const bool row_in[2] = {gy0 >= 0 && gy0 < gh, gy0 + 1 >= 0 && gy0 + 1 < gh};
-    float sx[4], sy[4], si[4], sd[4], s20[4];
-    for (int k = 0; k < 4; k++) {
-        int gx = gx0 + (k >> 1), gy = gy0 + (k & 1);
-        gx = gx < 0 ? 0 : (gx > gw - 1 ? gw - 1 : gx);
-        gy = gy < 0 ? 0 : (gy > gh - 1 ? gh - 1 : gy);
-        load(gx, gy, sx[k], sy[k], si[k], sd[k], s20[k]);
-        const bool in = col_ok[k >> 1] && row_in[k & 1];
-        q.floor_in[k] = in ? 0u : kKeySentinel + (uint32_t)k;
-        q.floor_edge[k] = (in && (k & 1) == 0) ? 0u : kKeySentinel + (uint32_t)k;
-    }
-    const f32x2 xf = f2_splat((float)x);
+    const bool col_ok[2] = {gx0 >= 0, gx0 + 1 < gw && xr != kCell / 2}; // (gx0 < gw and gx0 + 1 >= 0 always)
+    const bool row_in[2] = {gy0 >= 0, gy0 + 1 < gh};
+    float sx4[4], sy4[4], si[4], sd[4], s20[4];
+    for (int k = 0; k < 4; k++) load(k, gx0 + (k >> 1), gy0 + (k & 1), sx4[k], sy4[k], si[k], sd[k], s20[k]);
+    const f32x2 xq = f2_splat((float)x * 0.25f);
     for (int j = 0; j < 2; j++) {
-        const f32x2 ddx = f2_sub(f2_make(sx[2 * j], sx[2 * j + 1]), xf);
-        q.ax16[j] = f2_mul(f2_mul(ddx, ddx), f2_splat(0.0625f));
-        q.sy4[j] = f2_mul(f2_make(sy[2 * j], sy[2 * j + 1]), f2_splat(0.25f));
+        const f32x2 ddx4 = f2_sub(f2_make(sx4[2 * j], sx4[2 * j + 1]), xq);
+        const f32x2 a = f2_mul(ddx4, ddx4);
+        const bool in0 = col_ok[j] && row_in[0], in1 = col_ok[j] && row_in[1];
+        q.ax16[j] = f2_make(in0 ? a.x : kPickPenalty, in1 ? a.y : kPickPenalty);
+        q.ax16_edge[j] = f2_make(in0 ? a.x : kPickPenalty, kPickPenalty);
+        q.sy4[j] = f2_make(sy4[2 * j], sy4[2 * j + 1]);
         q.si[j] = f2_make(si[2 * j], si[2 * j + 1]);
         q.s20[j] = f2_make(s20[2 * j], s20[2 * j + 1]);
     }
@@ -289,8 +287,12 @@ struct FastPickTrace { // what a host-side check wants to see of a pick (tests/h
     float err;
     bool all_depth;
 };
-DSM_HD int pick_seed_fast(const PickCol &q, int y, float pix_i, float pix_d, int gw, FastPickTrace *trace = nullptr) {
-    const bool edge = y % kCell == kCell / 2;
+struct FastPick {
+    int seed;  // the reference's pick ...
+    bool sure; // ... if the bounds separate it from the runner-up; otherwise the caller runs pick_seed
+};
+DSM_HD FastPick pick_seed_fast(const PickCol &q, int y, float pix_i, float pix_d, int gw, FastPickTrace *trace = nullptr) {
+    const bool edge = (y & (kCell - 1)) == kCell / 2;
     // every live candidate has a mean depth (and the pixel a depth): per row offset that is known for the whole quadrant
     // (depth_ok); the upper row is out of play altogether for a pixel on the filter's edge
     const bool all_depth = pixel_has_inv_depth(pix_d) && q.depth_ok[0] && (q.depth_ok[1] || edge);
@@ -302,7 +304,7 @@ DSM_HD int pick_seed_fast(const PickCol &q, int y, float pix_i, float pix_d, int
     f32x2 c[2], dd20[2];
     for (int j = 0; j < 2; j++) {
         const f32x2 ddyq = f2_sub(q.sy4[j], yq);
-        const f32x2 dist16 = f2_fma(ddyq, ddyq, q.ax16[j]);
+        const f32x2 dist16 = f2_fma(ddyq, ddyq, edge ? q.ax16_edge[j] : q.ax16[j]);
         const f32x2 t = f2_mul(f2_sub(q.si[j], pi), tenth);
         const f32x2 c_no = f2_fma(t, t, dist16);
         dd20[j] = f2_fma(q.s20[j], mm, p20m);
@@ -310,33 +312,31 @@ DSM_HD int pick_seed_fast(const PickCol &q, int y, float pix_i, float pix_d, int
     }
     // Costs are >= 0, so their bit patterns order like the values; the candidate's position in the reference's scan goes
     // into the two lowest bits (a change of < 4 ulp, inside the error bound): the smallest tagged cost names the winner.
-    // A candidate out of play is lifted to a sentinel above every cost (its floor); a NaN cost has a bit pattern above the
-    // sentinels and never wins either, as it never wins the reference's '<'.  The pick is the reference's for sure if the
-    // ONE bound of the four -- the per-candidate bound (pixel_cost_fast) is monotone in the cost, in |dd20| and in |s20|, so
-    // at the largest of each it holds for every candidate, of a masked one too -- separates the winner from the runner-up
-    // and from the sentinel the scan starts from.
+    // A candidate out of play sits at 1e30 or above; a NaN cost has a bit pattern above every number and never wins either,
+    // as it never wins the reference's '<'.  The pick is the reference's for sure if ONE bound separates the winner from the
+    // runner-up and from the sentinel the scan starts from: the per-candidate bound (pixel_cost_fast) is monotone in the
+    // cost, in |dd20| and in |s20|, so taken at the runner-up's cost (it is the larger of the two; cut at 2e6: above that
+    // the second test decides alone) and at the largest |dd20| and |s20| of the four it holds for both -- and c - err(c)
+    // grows with c, so the third and fourth lie beyond the runner-up's lower end.
     const float ck[4] = {c[0].x, c[0].y, c[1].x, c[1].y};
-    const float c_max = fmaxf(fmaxf(ck[0], ck[1]), fmaxf(ck[2], ck[3])); // (a NaN cost drops out of the maximum)
     const float ad_max = fmaxf(fmaxf(fabsf(dd20[0].x), fabsf(dd20[0].y)), fmaxf(fabsf(dd20[1].x), fabsf(dd20[1].y)));
     uint32_t key[4];
-    for (int k = 0; k < 4; k++) {
-        const uint32_t tagged = (__builtin_bit_cast(uint32_t, ck[k]) & ~3u) | (uint32_t)k;
-        const uint32_t fl = edge ? q.floor_edge[k] : q.floor_in[k];
-        key[k] = tagged > fl ? tagged : fl;
-    }
-    const float err_max = fast_cost_err(c_max, fast_cost_slack(ad_max, q.df));
-    if (trace) { trace->err = err_max; trace->all_depth = all_depth; }
+    for (int k = 0; k < 4; k++) key[k] = (__builtin_bit_cast(uint32_t, ck[k]) & ~3u) | (uint32_t)k;
     const uint32_t lo01 = key[0] < key[1] ? key[0] : key[1], hi01 = key[0] < key[1] ? key[1] : key[0];
     const uint32_t lo23 = key[2] < key[3] ? key[2] : key[3], hi23 = key[2] < key[3] ? key[3] : key[2];
     const uint32_t first = lo01 < lo23 ? lo01 : lo23;
     const uint32_t mid_a = lo01 < lo23 ? lo23 : lo01, mid_b = hi01 < hi23 ? hi01 : hi23;
     const uint32_t second = mid_a < mid_b ? mid_a : mid_b;
-    const float c1 = __builtin_bit_cast(float, first), c2 = __builtin_bit_cast(float, second);
-    if (c1 + err_max < c2 - err_max && c1 + err_max < 1e6f) return q.base + (int)(first & 1u) * gw + (int)((first >> 1) & 1u);
-    return kPickUnsure;
+    const float c1 = __builtin_bit_cast(float, first), c2 = fminf(__builtin_bit_cast(float, second), 2e6f); // (fminf drops a NaN)
+    const float err = fast_cost_err(c2, fast_cost_slack(ad_max, q.df));
+    if (trace) { trace->err = err; trace->all_depth = all_depth; }
+    FastPick r;
+    r.seed = q.base + (int)(first & 1u) * gw + (int)((first >> 1) & 1u);
+    r.sure = c1 + err < c2 - err && c1 + err < 1e6f;
+    return r;
 }
 template <typename LoadSeedF>
-DSM_HD int pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeedF load, FastPickTrace *trace = nullptr) {
+DSM_HD FastPick pick_seed_fast(int x, int y, float pix_i, float pix_d, int gw, int gh, LoadSeedF load, FastPickTrace *trace = nullptr) {
     return pick_seed_fast(pick_col(x, y, gw, gh, load), y, pix_i, pix_d, gw, trace);
 }
 
@@ -562,6 +562,21 @@ DSM_HD void gn_step(double *H, const double *J, float &nx, float &ny, float &nz,
     nz = (float)((double)nz - u[2]);
     nb = (float)((double)nb - u[3]);
 }
+
+// Gauss-Newton steps whose Jacobian sums are NOT taken in the reference's order -- where that provably changes nothing
+// (round 6; k_seed_fit, steps 2..5).  Every term of J(a) = 2 sum_i (double)(r_i * p_i,a) is formed exactly as the reference
+// forms it: an fp32 product widened to double.  The terms are fp32 values, every one a multiple of the granule
+// g = 2^(floor(log2 min|t|) - 23) of the smallest non-zero one, and while sum|t| < 2^53 g every partial sum of every order is a
+// multiple of g below 2^53 g -- a double -- so NO addition rounds and all orders give the same bits.  With 2^floor(log2 x) > x / 2
+// that is  sum|t| < 2^29 min|t|,  tested as  sum|t| * 2^-28 < min|t|  (a factor 2 for the fp32 roundings of sum|t|, which
+// the kernel accumulates in fp32: n 2^-24 relative, n <= 232); a sum that overflowed to +inf or holds a NaN fails it, an
+// all-zero list passes (min = +inf: the sum is 0 in any order).  tests/hostemu.cpp: 99.8 % of the steps that qualify (Huber
+// classes unchanged, all in the core) pass for all four components, and their free-order sums ARE the ordered sums, bit for bit.
+DSM_HD bool gn_sum_is_exact(float t_abs_sum, float t_abs_min_nonzero) { return t_abs_sum * 3.7252902984619140625e-9f < t_abs_min_nonzero; }
+// the smallest non-zero magnitude by an unsigned minimum: (bits(t) << 1) - 1 drops the sign, keeps the order of the non-zero
+// magnitudes and sends +-0 to the top (0xffffffff) -- one shift-and-add per term; gn_min_key_value undoes it (the top -> +inf)
+DSM_HD uint32_t gn_min_key(float t) { return (__builtin_bit_cast(uint32_t, t) << 1) - 1u; }
+DSM_HD float gn_min_key_value(uint32_t key) { return key == 0xffffffffu ? __builtin_inff() : __builtin_bit_cast(float, (key + 1u) >> 1); }
 
 // tail of get_huber_norm, FF.cpp:182-187
 DSM_HD void plane_finish(float &nx, float &ny, float &nz, float &nb, float mx, float my, float mz) {

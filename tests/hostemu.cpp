@@ -6,6 +6,7 @@
 // never loaded by the product package.
 //
 // Build: g++ -std=c++17 -O2 -ffp-contract=off -shared -fPIC tests/hostemu.cpp -o tests/_build/libhostemu.so
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -43,6 +44,10 @@ struct Emu {
     // qualify, [2] steps 2..5 counted, [3] qualifying sums whose tree-order value differs from the ordered one (must be 0),
     // [4] all-core steps
     long long exact_stats[5] = {0, 0, 0, 0, 0};
+    // k_seed_fit's free-order steps (dsm_math.h, gn_sum_is_exact): [0] steps 2..5 that qualify (all-core, classes unchanged: the
+    // cached inverse is reused), [1] of them with all four Jacobian sums provably exact in any order, [2] of those, sums that
+    // differ from the ordered sums all the same (must be 0)
+    long long cert_stats[3] = {0, 0, 0};
     long long exact_operand_pass = 0; // steps 2..5 that pass the cheaper OPERAND-level test: range(r) + range(p_a) + 1 <= 21 for every a
     long long fast_total = 0, fast_unsure = 0, fast_mismatches = 0, fast_checked = 0, fast_bound_violations = 0; // pick_seed_fast
     long long unsure_by_sweep[kSweeps] = {0, 0, 0};
@@ -97,11 +102,16 @@ void assign(Emu &e, bool first) {
         // the kernel's filtered pick (dsm_math.h, pick_seed_fast): wherever it answers, it must be the reference's pick
         FastPickTrace trace = {0.0f, false};
         const float p20 = pixel_has_inv_depth(e.D(x, y)) ? pixel_p20(e.D(x, y)) : 0.0f; // (the host's model of v_rcp_f32: a hash-chosen ulp off)
-        const int fast = pick_seed_fast(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
-                                        [&](int gx, int gy, float &sx, float &sy, float &si, float &sd, float &s20) {
+        const FastPick fast = pick_seed_fast(x, y, e.I(x, y), e.D(x, y), e.gw, e.gh,
+                                        [&](int, int gx, int gy, float &sx4, float &sy4, float &si, float &sd, float &s20) {
+                                            const bool inside = gx >= 0 && gx < e.gw && gy >= 0 && gy < e.gh;
+                                            gx = gx < 0 ? 0 : (gx > e.gw - 1 ? e.gw - 1 : gx); // (outside the grid: the nearest cell inside)
+                                            gy = gy < 0 ? 0 : (gy > e.gh - 1 ? e.gh - 1 : gy);
                                             const int s = gy * e.gw + gx;
-                                            sx = e.core[s].x; sy = e.core[s].y; si = e.core[s].i;
+                                            const float sx = e.core[s].x, sy = e.core[s].y;
+                                            sx4 = sx * 0.25f; sy4 = sy * 0.25f; si = e.core[s].i;
                                             sd = e.core[s].d; s20 = seed_s20(sd, e.inv_depth[s]);
+                                            if (!inside) return;
                                             const bool hd = sd > 0;
                                             // ... and its error bound must hold against the reference's typed costs
                                             const float invd = pixel_inv_depth(e.D(x, y));
@@ -115,25 +125,38 @@ void assign(Emu &e, bool first) {
                                                 if (!(fabs((double)f.c - ref) <= (double)f.err)) e.fast_bound_violations++;
                                             }
                                         }, &trace);
-        {
-            // the ONE bound the four candidates share must be at least every candidate's own (masked ones included: the cells
-            // pick_col clamps into the grid)
+        if (fast.sure) {
+            // the ONE bound the pick was decided with must cover the distance between the filter's cost and the reference's typed
+            // cost for every candidate in play whose cost lies at or below the runner-up's (cut at 2e6) -- the winner and the
+            // runner-up among them
             const int gx0 = x / kCell - (x % kCell < kCell / 2 ? 1 : 0), gy0 = y / kCell - (y % kCell < kCell / 2 ? 1 : 0);
+            const float invd = pixel_inv_depth(e.D(x, y));
+            float cf[4], cr[4], cs[4];
+            int n_in = 0;
             for (int k = 0; k < 4; k++) {
-                int gx = gx0 + (k >> 1), gy = gy0 + (k & 1);
-                gx = gx < 0 ? 0 : (gx > e.gw - 1 ? e.gw - 1 : gx);
-                gy = gy < 0 ? 0 : (gy > e.gh - 1 ? e.gh - 1 : gy);
+                const int gx = gx0 + (k >> 1), gy = gy0 + (k & 1);
+                const bool in = gx >= 0 && gx < e.gw && gy >= 0 && gy < e.gh && abs(gx * kCell + kCell / 2 - x) < kCell && abs(gy * kCell + kCell / 2 - y) < kCell;
+                if (!in) continue;
                 const int s = gy * e.gw + gx;
-                const FastCost f = pixel_cost_fast(e.core[s].x, e.core[s].y, e.core[s].i, seed_s20(e.core[s].d, e.inv_depth[s]), trace.all_depth,
-                                                   e.I(x, y), p20, x, y);
+                cf[n_in] = pixel_cost_fast(e.core[s].x, e.core[s].y, e.core[s].i, seed_s20(e.core[s].d, e.inv_depth[s]), trace.all_depth, e.I(x, y), p20, x, y).c;
+                float cn, cd;
+                pixel_cost(e.core[s].x, e.core[s].y, e.core[s].i, e.core[s].d > 0, e.inv_depth[s], e.I(x, y), invd, x, y, cn, cd);
+                cr[n_in] = trace.all_depth ? cd : cn;
+                cs[n_in] = cf[n_in];
+                n_in++;
+            }
+            std::sort(cs, cs + n_in);
+            const float c2 = n_in > 1 ? std::min(cs[1], 2e6f) : 2e6f;
+            for (int k = 0; k < n_in; k++) {
+                if (!(cf[k] <= c2)) continue;
                 e.fast_checked++;
-                if (f.err == f.err && !(f.err <= trace.err)) e.fast_bound_violations++;
+                if (!(fabs((double)cf[k] - (double)cr[k]) <= (double)trace.err)) e.fast_bound_violations++;
             }
         }
         e.fast_total++;
-        if (fast == kPickUnsure) { e.fast_unsure++; e.unsure_by_sweep[(e.sweep_id - 1) % kSweeps]++; e.unsure_waves.insert(((long long)e.sweep_id << 40) | (long long)(y * ((e.w + 63) / 64) + x / 64)); }
-        else if (fast != exact) e.fast_mismatches++;
-        const int pick = fast == kPickUnsure ? exact : fast;
+        if (!fast.sure) { e.fast_unsure++; e.unsure_by_sweep[(e.sweep_id - 1) % kSweeps]++; e.unsure_waves.insert(((long long)e.sweep_id << 40) | (long long)(y * ((e.w + 63) / 64) + x / 64)); }
+        else if (fast.seed != exact) e.fast_mismatches++;
+        const int pick = fast.sure ? fast.seed : exact;
         if (first) { e.label[p] = pick; continue; }
         e.cand[p] = pick;
         const int l = e.label[p];
@@ -318,6 +341,34 @@ void seed_planes(Emu &e) {
                     }
                     if (it == 0 && sums_ok) e.exact_stats[0]++;
                     if (it > 0) { e.exact_stats[2]++; if (sums_ok) e.exact_stats[1]++; }
+                    if (it > 0 && all_core && same) {
+                        // the kernel's form of this step (k_seed_fit, round 6): J summed as four interleaved partial sums per
+                        // component (blocks of eight elements dealt out in turn), used only where the test of dsm_math.h says
+                        // that no addition of any order rounds -- then it must BE the ordered sum
+                        e.cert_stats[0]++;
+                        bool exact = true;
+                        double Jt[4];
+                        for (int a = 0; a < 4; a++) {
+                            double part[4] = {0, 0, 0, 0};
+                            float pabs[4] = {0, 0, 0, 0};
+                            uint32_t pmin[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                            for (int i = 0; i < m; i++) {
+                                const float pa = a < 3 ? lp[i * 3 + a] : 1.0f;
+                                const float t = res[i] * pa;
+                                part[(i >> 3) & 3] += (double)t;
+                                pabs[(i >> 3) & 3] += fabsf(t);
+                                const uint32_t key = gn_min_key(t);
+                                pmin[(i >> 3) & 3] = key < pmin[(i >> 3) & 3] ? key : pmin[(i >> 3) & 3];
+                            }
+                            Jt[a] = 2.0 * ((part[0] + part[2]) + (part[1] + part[3]));
+                            const uint32_t kmin = std::min(std::min(pmin[0], pmin[2]), std::min(pmin[1], pmin[3]));
+                            exact = exact && gn_sum_is_exact((pabs[0] + pabs[2]) + (pabs[1] + pabs[3]), gn_min_key_value(kmin));
+                        }
+                        if (exact) {
+                            e.cert_stats[1]++;
+                            if (memcmp(Jt, acc + 16, sizeof Jt) != 0) e.cert_stats[2]++;
+                        }
+                    }
                     gn_step(acc, acc + 16, nx, ny, nz, nb);
                 }
                 if (changed_any) e.gn_seeds_mask_changed++;
@@ -418,6 +469,7 @@ void *emu_create(int w, int h, float fx, float fy, float cx, float cy, float far
 }
 void emu_destroy(void *p) { delete (Emu *)p; }
 void emu_set_order_salt(void *p, int salt) { ((Emu *)p)->order_salt = salt; }
+void emu_cert_stats(void *p, long long *out) { for (int i = 0; i < 3; i++) out[i] = ((Emu *)p)->cert_stats[i]; }
 void emu_exact_sum_stats(void *p, long long *out) { for (int i = 0; i < 5; i++) out[i] = ((Emu *)p)->exact_stats[i]; out[5] = ((Emu *)p)->exact_operand_pass; }
 // pick_seed_fast over every pixel assigned so far: out[24] (12..14: undecided picks by sweep; 7: seeds with a non-core residual at step 1; 8..11: fitted seeds, seeds with a class change after step 1, steps 2..5, steps with a change);
 // out[0..7] = [pixels, unsure, answered differently from pick_seed, costs checked,

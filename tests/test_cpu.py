@@ -187,6 +187,15 @@ def test_gpu_formulation_on_host(ob, synth, hostemu_lib, camera, frames, salt, s
     emu.lib.emu_exact_sum_stats(emu.h, ex)
     assert ex[3] == 0, f"{ex[3]} qualifying sums whose tree-order value differs from the ordered one"
     assert stereo or ex[2] == 0 or ex[1] >= 0.95 * ex[2], (ex[1], ex[2])  # (a statistic of the smooth scenes; NaN / inf planes never qualify)
+    # k_seed_fit's free-order steps (round 6; dsm_math.h, gn_sum_is_exact): steps 2..5 of a seed whose Huber classes stand take
+    # their Jacobian sums in four interleaved parts wherever a cheap test proves that no addition of any order rounds --
+    # never a different sum, and nearly always a pass
+    ct = (C.c_longlong * 3)()
+    emu.lib.emu_cert_stats.argtypes = [C.c_void_p, C.c_void_p]
+    emu.lib.emu_cert_stats(emu.h, ct)
+    assert ct[2] == 0, f"{ct[2]} steps whose sums pass the exactness test and still differ from the ordered sums"
+    assert ct[0] == 0 or ct[1] >= 0.99 * ct[0], (ct[1], ct[0])
+    print(f"free-order steps: {ct[1]} of {ct[0]} qualifying steps 2..5 pass the exactness test for all four sums; every one equals the ordered sums")
     print(f"exact sums: steps 2..5 whose Jacobian sums all span <= 21 binades: {ex[1]} of {ex[2]}; step-1 (H and J): {ex[0]} of {st[8]} seeds; tree == ordered on all")
     print(f"plane fit: {st[7]} of {st[8]} seeds with a residual outside the Huber core at step 1, {st[9]} with a class change later")
     print(f"pick_seed_fast: {unsure} of {pixels} pixels unsure ({100.0 * unsure / pixels:.3f} %), {checked} costs within their bound")
