@@ -519,7 +519,7 @@ template <int TIER> struct FitShape {
 // the group of seeds s0 .. s0+3 on one wave
 template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *__restrict__ c, int s0,
                                                              float (*s_col)[kFitCols][FitShape<TIER>::kStride], float *s_ones,
-                                                             double (*s_solver)[52]) {
+                                                             double (*s_solver)[52], float4 *s_plane) {
     constexpr int kChunks = FitShape<TIER>::kChunks;
     const int lane = lane_id(), g = lane >> 4, gl = lane & (kFitLanes - 1);
     const int S = c->n_seed;
@@ -651,77 +651,88 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
             }
         stamp(c, 4, s0, 2, lane);
         unsigned long long h_masks[4] = {0, 0, 0, 0}; // class masks (this lane's seed) the cached inverse was built from
+        bool h_all_core = false;                      // ... and whether they were empty for all four seeds (wave-uniform)
         for (int it = 0; it < 5; it++) {
             if (it == 1) stamp(c, 4, s0, 3, lane);
-            // residuals and Huber classes of every seed's list, lane-parallel; the class masks of a seed stay with its lanes
-            unsigned long long noncore[4] = {0, 0, 0, 0};
-            float pn[kFitSeeds][4]; // every seed's plane, wave-uniform
+            // residuals and Huber classes of every seed's list, lane-parallel.  The class masks are wave-uniform values (a
+            // ballot each); a seed's lanes take theirs only on a step that has an outlier somewhere (any_out)
+            unsigned long long out_mask[kFitSeeds][kChunks];
+            bool any_out = false;
+            // every seed's plane: each group's first lane leaves its four floats in LDS, every lane reads all sixteen (four
+            // 16-byte reads instead of sixteen cross-lane moves: the instructions of this kernel are what it is short of)
+            if (gl == 0) s_plane[g] = make_float4(nx, ny, nz, nb);
+            wave_lds_sync();
+            float pn[kFitSeeds][4];
 #pragma unroll
             for (int q = 0; q < kFitSeeds; q++) {
-                pn[q][0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nx), q * kFitLanes));
-                pn[q][1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ny), q * kFitLanes));
-                pn[q][2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nz), q * kFitLanes));
-                pn[q][3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nb), q * kFitLanes));
+                const float4 v = s_plane[q];
+                pn[q][0] = v.x; pn[q][1] = v.y; pn[q][2] = v.z; pn[q][3] = v.w;
             }
-            // elements 0..63 of all four lists without a branch in between: four independent instruction streams for
-            // the scheduler to interleave (a wave of this kernel has few neighbours to hide its latencies behind)
-#pragma unroll
-            for (int q = 0; q < kFitSeeds; q++) {
-                const bool valid = lane < mg[q];
-                const float r = pq[q][0][0] * pn[q][0] + pq[q][0][1] * pn[q][1] + pq[q][0][2] * pn[q][2] + pn[q][3];
-                // Huber class (huber_class32) as selects: the residual column carries r for a core element and the tail
-                // sign for an outlier, 0 for a NaN residual (see fit_ordered_sum)
-                const bool in_core = fabsf(r) < hr_above;
-                const float tail_v = r >= hr_above ? 1.0f : (r <= -hr_above ? -1.0f : 0.0f);
-                if (valid) s_col[q][3][lane] = in_core ? r : tail_v;
-                const unsigned long long mask = __ballot(valid && !in_core);
-                if (g == q) noncore[0] = mask;
-            }
+            // the residuals of all four lists, 64 elements of a list at a time; the residual column carries r for a core element
+            // and the tail sign for an outlier, 0 for a NaN residual (huber_class32 as selects, see fit_ordered_sum) -- formed only
+            // where a chunk has an outlier at all (wave-uniform: after the first step practically never)
 #pragma unroll
             for (int q = 0; q < kFitSeeds; q++) {
 #pragma unroll
-                for (int k = 1; k < kChunks; k++) {
-                    if (k * 64 < mg[q]) { // wave-uniform
+                for (int k = 0; k < kChunks; k++) {
+                    if (k == 0 || k * 64 < mg[q]) { // wave-uniform
                         const int i = k * 64 + lane;
                         const bool valid = i < mg[q];
                         const float r = pq[q][k][0] * pn[q][0] + pq[q][k][1] * pn[q][1] + pq[q][k][2] * pn[q][2] + pn[q][3];
                         const bool in_core = fabsf(r) < hr_above;
-                        const float tail_v = r >= hr_above ? 1.0f : (r <= -hr_above ? -1.0f : 0.0f);
-                        if (valid) s_col[q][3][i] = in_core ? r : tail_v;
                         const unsigned long long mask = __ballot(valid && !in_core);
-                        if (g == q) noncore[k] = mask;
+                        out_mask[q][k] = mask;
+                        if (mask == 0) {
+                            if (valid) s_col[q][3][i] = r;
+                        } else {
+                            const float tail_v = r >= hr_above ? 1.0f : (r <= -hr_above ? -1.0f : 0.0f);
+                            if (valid) s_col[q][3][i] = in_core ? r : tail_v;
+                            any_out = true;
+                        }
+                    } else {
+                        out_mask[q][k] = 0;
                     }
                 }
+            }
+            unsigned long long noncore[4] = {0, 0, 0, 0};
+            if (any_out) {
+#pragma unroll
+                for (int q = 0; q < kFitSeeds; q++)
+#pragma unroll
+                    for (int k = 0; k < kChunks; k++)
+                        if (g == q) noncore[k] = out_mask[q][k];
             }
             wave_lds_sync();
             // The Hessian sums read nothing but the points and which elements are in the Huber core: while the class
             // masks of all four seeds stay what they were when H was last summed (from the second step on they are
             // normally all-core), H, its damped inverse and the determinant are bit for bit the same, and the
             // inverse still sits in LDS: only J is new.
-            bool same = it > 0;
+            bool reuse_inverse = it > 0 && h_all_core && !any_out; // (all empty then and now: nothing to compare)
+            if (it > 0 && !h_all_core && any_out) { // (outliers then and now: the same ones?  One side empty and the other not: they differ)
+                bool same = true;
 #pragma unroll
-            for (int k = 0; k < 4; k++) same = same && noncore[k] == h_masks[k];
-            const bool reuse_inverse = __ballot(!same) == 0;
+                for (int k = 0; k < 4; k++) same = same && noncore[k] == h_masks[k];
+                reuse_inverse = __ballot(!same) == 0;
+            }
             // ... and then only four of a seed's sixteen lanes have a sum to take.  Round 6: all sixteen take a QUARTER of one
-            // -- lane gl = component (gl & 3) of J, blocks of eight elements gl >> 2, + 4, + 8, ... -- wherever the order of a sum
+            // -- lane gl = component (gl & 3) of J, blocks of four elements gl >> 2, + 4, + 8, ... -- wherever the order of a sum
             // provably does not matter: every term is the reference's own fp32 product widened to double, and while the
             // magnitudes of a sum's terms span less than 2^29 no addition of any order rounds (dsm_math.h, gn_sum_is_exact:
             // 99.8 % of these steps; tests/hostemu.cpp).  A lane carries sum|t| and the smallest non-zero |t| beside its
             // quarter; if every sum of all four seeds passes, J is the ordered J bit for bit -- else the ordered sums run.
             bool have_j = false;
-            if (reuse_inverse && __ballot((noncore[0] | noncore[1] | noncore[2] | noncore[3]) != 0) == 0) {
+            if (reuse_inverse && !any_out) {
                 const int a = gl & 3;
                 const float *rc = s_col[g][3], *pc = a == 3 ? s_ones : s_col[g][a];
                 const int ps = a == 3 ? 0 : 1;
                 double part = 0.0;
                 float t_sum = 0.0f;
                 uint32_t t_min = 0xffffffffu;
-                for (int b = (gl >> 2) * 8; b < m8; b += 32) {
-                    const float4 xa = *reinterpret_cast<const float4 *>(rc + b), xb = *reinterpret_cast<const float4 *>(rc + b + 4);
-                    const float4 ya = *reinterpret_cast<const float4 *>(pc + b * ps), yb = *reinterpret_cast<const float4 *>(pc + b * ps + 4);
-                    const float t[8] = {xa.x * ya.x, xa.y * ya.y, xa.z * ya.z, xa.w * ya.w, xb.x * yb.x, xb.y * yb.y, xb.z * yb.z, xb.w * yb.w};
+                for (int b = (gl >> 2) * 4; b < m8; b += 16) { // (blocks of four: the quarters differ by at most one block)
+                    const float4 xa = *reinterpret_cast<const float4 *>(rc + b), ya = *reinterpret_cast<const float4 *>(pc + b * ps);
+                    const float t[4] = {xa.x * ya.x, xa.y * ya.y, xa.z * ya.z, xa.w * ya.w};
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
+                    for (int q = 0; q < 4; q++) {
                         part += (double)t[q];
                         t_sum += fabsf(t[q]);
                         const uint32_t key = gn_min_key(t[q]);
@@ -745,6 +756,7 @@ template <int TIER> __device__ __forceinline__ void fit_group(const DeviceCtx *_
             if (!reuse_inverse) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) h_masks[k] = noncore[k];
+                h_all_core = !any_out;
                 // damped solve, FF.cpp:172-180: one lane per 2x2 determinant, per adjugate entry, per row -- per seed
                 if (gl < 10) {
                     // H(3,3) += 2 per core element (FF.cpp:150): an integer, no sum needed
@@ -846,15 +858,16 @@ template <bool BATCH, int TIER> __global__ __launch_bounds__(64) void k_seed_fit
     __shared__ __attribute__((aligned(16))) float s_col[kFitSeeds][kFitCols][FitShape<TIER>::kStride];
     __shared__ __attribute__((aligned(16))) float s_ones[8];
     __shared__ double s_solver[kFitSeeds][52]; // per seed: [16] damped H | [12] 2x2 dets | [16] inverse | [4] J | [4] update
+    __shared__ float4 s_plane[kFitSeeds];      // per seed: the plane of the step being taken
     if (TIER == kFitLarge) {
         const int n_big = c->fit_big_count[0];
         for (int e = blk.x; e < n_big; e += kFitLargeBlocks) {
-            fit_group<TIER>(c, c->worklist[e] * kFitSeeds, s_col, s_ones, s_solver);
+            fit_group<TIER>(c, c->worklist[e] * kFitSeeds, s_col, s_ones, s_solver, s_plane);
             wave_lds_sync();
         }
     } else {
         const int n_groups = (c->n_seed + kFitSeeds - 1) / kFitSeeds;
-        fit_group<TIER>(c, (n_groups - 1 - blk.x) * kFitSeeds, s_col, s_ones, s_solver); // bottom rows (long lists) first, see seed_of_block
+        fit_group<TIER>(c, (n_groups - 1 - blk.x) * kFitSeeds, s_col, s_ones, s_solver, s_plane); // bottom rows (long lists) first, see seed_of_block
     }
 }
 
