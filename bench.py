@@ -348,6 +348,31 @@ def self_launch(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+class stdout_to_stderr:
+    """fd-level: what native libraries print to stdout inside the block goes to stderr (RCCL prints a version banner when a
+    communicator is created or destroyed; the contract is ONE JSON line on stdout)"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def close_group(dist, world):
+    if dist is None:
+        return
+    with stdout_to_stderr():
+        if world > 1:
+            dist.barrier()  # (rank 0 may still have been checking its maps against the oracle)
+        dist.destroy_process_group()
+
+
 def open_group(args, world, rank, local_rank):
     """Device of this rank and the process group of the final merge -> (torch, device, dist or None, device of the collectives'
     tensors, why there is no group).  DSM_BENCH_BACKEND=gloo + DSM_BENCH_ONE_DEVICE=1 run the multi-rank logic on a single GPU
@@ -364,7 +389,8 @@ def open_group(args, world, rank, local_rank):
     if world > 1 or not args.no_rccl_world1:
         from densesurfelmapping_amd.replay import init_collective
         try:
-            dist = init_collective(backend, world, rank, device)
+            with stdout_to_stderr():
+                dist = init_collective(backend, world, rank, device)
         except Exception as e:  # noqa: BLE001 -- a group of one is an extra; a world of several cannot do without
             if world > 1:
                 raise
@@ -434,7 +460,8 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
     if dist is not None:
         cloud = eng.cloud_tensor(torch, f"cuda:{device}").to(coll_dev)
         try:
-            rp.merge_clouds(cloud[:44])  # communicator warm-up
+            with stdout_to_stderr():
+                rp.merge_clouds(cloud[:44])  # communicator warm-up
             torch.cuda.synchronize()
             t_m = time.perf_counter()
             merged, counts = rp.merge_clouds(cloud)
@@ -508,12 +535,9 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
     out["e2e_hbm_frac"] = round(fps * (9 * n_pix + 60 * n_seed + 88 * m_mean + 44 * 1400.0) / 1e9 / (HBM_PEAK_GBS * world), 5)
     eng.close()
     src.close()
+    close_group(dist, world)
     if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        if world > 1:
-            dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
 
 
 def main():
@@ -745,7 +769,8 @@ def main():
         mine = torch.cat(clouds).to(coll_dev)
         del clouds
         try:
-            merge_clouds(mine[:44])  # communicator warm-up (first-collective setup is not the merge)
+            with stdout_to_stderr():
+                merge_clouds(mine[:44])  # communicator warm-up (first-collective setup is not the merge)
             torch.cuda.synchronize()
             t_m = time.perf_counter()
             merged, counts = merge_clouds(mine)
@@ -942,7 +967,8 @@ def main():
                                         "note": "dsm_fuse_map as SurfelMap::fuse_map calls it: pageable host image, depth and surfel vector in, "
                                                 "updated vector out, synchronous; per frame the frame goes up through page-locked staging, the "
                                                 "vector is compared with what the previous call returned (and uploaded only if the caller "
-                                                "changed it), the whole map comes back"}
+                                                "changed it), of the map only the 64-record groups the frame changed come back (delta download)",
+                                        "delta_download": ff.debug_dropin_stats()}
         ff.close()
     if leg_on("fullhd"):
         # BASELINE configs[4]: 1920x1080 depth stream against >= 2 M live surfels, and the loop-closure deformation
@@ -1505,14 +1531,11 @@ def main():
 
     for job in oracle_jobs:  # (the verification block did not run: e.g. --mode streams)
         job.kill()
-    if rank == 0:
-        print(json.dumps(out))
     for ff in handles:
         ff.close()
-    if dist is not None:
-        if world > 1:
-            dist.barrier()  # (rank 0 may still have been checking its maps against the oracle)
-        dist.destroy_process_group()
+    close_group(dist, world)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -54,7 +54,7 @@ ABI_SYMBOLS = (
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
     "dsm_batch_replay_timed",
-    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps", "dsm_debug_set_fit_small_cap", "dsm_debug_tier_counts",
+    "dsm_get_labels", "dsm_get_seeds", "dsm_seed_count", "dsm_replay_timed", "dsm_debug_wave_stamps", "dsm_debug_set_fit_small_cap", "dsm_debug_tier_counts", "dsm_debug_dropin_stats",
     "dsm_debug_run_stages", "dsm_debug_get_label_buffer", "dsm_debug_set_label_buffer", "dsm_debug_get_seed_state",
     "dsm_debug_set_seed_state",
 )
@@ -146,6 +146,7 @@ def load_library():
     lib.dsm_debug_wave_stamps.argtypes = [_vp, _vp]
     lib.dsm_debug_set_fit_small_cap.argtypes = [_vp, C.c_int32]
     lib.dsm_debug_tier_counts.argtypes = [_vp, _vp]
+    lib.dsm_debug_dropin_stats.argtypes = [_vp, _vp]
     lib.dsm_debug_run_stages.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]
     lib.dsm_debug_get_label_buffer.argtypes = [_vp, C.c_int, _vp]
     lib.dsm_debug_set_label_buffer.argtypes = [_vp, C.c_int, _vp]
@@ -488,6 +489,13 @@ class FusionFunctions:
         self._check(self._lib.dsm_debug_tier_counts(self._h, out.ctypes.data_as(_vp)))
         return {"huber_rest_by_sweep": [int(out[0]), int(out[2]), int(out[4])], "long_list_by_sweep": [int(out[1]), int(out[3]), int(out[5])],
                 "fit_long_groups": int(out[6])}
+
+    def debug_dropin_stats(self):
+        """the drop-in calls' delta downloads so far (include/dsm.h, dsm_debug_dropin_stats)"""
+        out = np.zeros(8, np.int64)
+        self._check(self._lib.dsm_debug_dropin_stats(self._h, out.ctypes.data_as(_vp)))
+        return {"calls": int(out[0]), "delta_calls": int(out[1]), "delta_groups": int(out[2]), "last_groups": int(out[3]),
+                "host_us": {"frame_staging": int(out[4]), "map_compare_or_upload": int(out[5]), "gpu_wait": int(out[6]), "fetch_and_patch": int(out[7])}}
 
     def debug_set_fit_small_cap(self, cap):
         self._check(self._lib.dsm_debug_set_fit_small_cap(self._h, int(cap)))

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -160,7 +161,8 @@ struct dsm_handle {
     hipEvent_t ev_params = nullptr;
     std::vector<void *> allocs; // every hipMalloc of this handle
     FrameParams *h_params = nullptr; // pinned staging ring
-    int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch
+    int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch, [4] delta groups; [64..127] the device's scalar block as it came
+    int32_t *d_scalars = nullptr;    // the device's scalar block (64 ints: n_local @8, n_local_next @16, n_new @24, n_holes @32, status @48, delta count @56)
     FrameParams *d_params = nullptr;
     uint8_t *d_stage_img = nullptr; // one tightly packed frame on its way into a pitched slot
     float *d_stage_depth = nullptr;
@@ -230,10 +232,18 @@ struct dsm_handle {
     size_t store_tmp_bytes = 0;
     int store_cap = 0, store_n = 0;
     // drop-in calls (dsm_fuse_map / dsm_fuse_initialize_map): page-locked staging owned by the handle
-    uint8_t *pin_frame = nullptr; // one frame, image then depth, tightly packed rows
+    uint8_t *pin_frame = nullptr; // one frame, image then depth, rows at the frame slots' pitch
     dsm_surfel *pin_map = nullptr; // shadow of the caller's array: what the last drop-in call returned == the device map
     size_t pin_map_cap = 0;
     int shadow_n = -1;             // -1: the device map is not known to equal the shadow (resident calls in between)
+    // delta download: the 64-record groups a frame changed, packed by k_delta_pack (device), and their page-locked landing place
+    dsm_surfel *d_delta = nullptr, *pin_delta = nullptr;
+    int32_t *d_delta_idx = nullptr, *pin_delta_idx = nullptr;
+    int delta_cap_groups = 0;
+    bool dirty_flags_clean = false; // every DeviceCtx::grp_dirty flag is 0 (true after a drop-in call; any other frame may set some)
+    int64_t dropin_calls = 0, dropin_delta_calls = 0, dropin_delta_groups = 0; // (statistics: dsm_debug_dropin_stats)
+    int dropin_last_groups = 0; // groups the previous drop-in call brought back: sizes the next call's first transfer
+    double dropin_us[4] = {0, 0, 0, 0}; // host time of the drop-in calls so far: frame staging | map compare / upload | wait for the GPU | patching the host copies
     HostPool *pool = nullptr;
     std::string err;
 };
@@ -448,6 +458,7 @@ int capture(dsm_handle *h, const DeviceCtx &ctx, bool with_compaction, int lo, i
 // frame's pipeline stream, fuse + tail on the map stream
 int submit_frame(dsm_handle *h, bool with_compaction) {
     h->shadow_n = -1;
+    h->dirty_flags_clean = false;
     h->reads_untracked = true; // (dsm_replay_enqueue, which lists what it reads, puts the flag back)
     if (int rc = map_grows(h, 1)) return rc;
     const int p = (int)(h->frames_submitted % h->n_pipe);
@@ -517,6 +528,7 @@ bool group_path(const dsm_handle *h) {
 }
 int submit_group(dsm_handle *h) {
     h->shadow_n = -1;
+    h->dirty_flags_clean = false;
     h->reads_untracked = true;
     const int G = group_size(h);
     if (int rc = map_grows(h, G)) return rc;
@@ -578,6 +590,7 @@ int submit_group(dsm_handle *h) {
 // run some or all stages of the next frame serially on the map stream (timed replays, state-level taps)
 int submit_serial(dsm_handle *h, bool with_compaction, hipEvent_t *ev, int lo, int hi) {
     h->shadow_n = -1;
+    h->dirty_flags_clean = false;
     h->reads_untracked = true;
     const int p = (int)(h->frames_submitted % h->n_pipe);
     dsm_handle::Pipe &pp = h->pipe[p];
@@ -663,39 +676,128 @@ bool par_equal(dsm_handle *h, const void *a, const void *b, size_t bytes) {
 
 // page-locked staging of the drop-in calls, grown on demand
 int dropin_reserve(dsm_handle *h, size_t map_records) {
-    if (!h->pool) h->pool = new HostPool(3);
-    if (!h->pin_frame) HIP_TRY(h, hipHostMalloc((void **)&h->pin_frame, (size_t)h->hc.w * h->hc.h * 5, hipHostMallocDefault));
+    if (!h->pool) { // the caller + up to seven helpers for the page-sized host copies and compares (a quarter of the machine at most)
+        const unsigned hw = std::thread::hardware_concurrency();
+        h->pool = new HostPool(hw >= 32 ? 7 : hw >= 8 ? 3 : 1);
+    }
+    if (!h->pin_frame) {
+        HIP_TRY(h, hipHostMalloc((void **)&h->pin_frame, (size_t)h->hc.pitch * h->hc.h * 5, hipHostMallocDefault));
+        memset(h->pin_frame, 0, (size_t)h->hc.pitch * h->hc.h * 5); // (the pad columns travel with the rows; no kernel reads them)
+    }
     if (map_records > h->pin_map_cap) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         size_t cap = h->pin_map_cap ? h->pin_map_cap : (size_t)1 << 16;
         while (cap < map_records) cap *= 2;
         dsm_surfel *n = nullptr;
         HIP_TRY(h, hipHostMalloc((void **)&n, cap * sizeof(dsm_surfel), hipHostMallocDefault));
-        if (h->pin_map) (void)hipHostFree(h->pin_map);
+        if (h->pin_map) HIP_TRY(h, hipHostFree(h->pin_map));
         h->pin_map = n;
         h->pin_map_cap = cap;
         h->shadow_n = -1;
+        // the delta download's buffers, sized for the same extent: every 64-record group of it may change in one frame
+        const size_t groups = cap / 64 + 1;
+        if (h->d_delta) HIP_TRY(h, hipFree(h->d_delta));
+        if (h->d_delta_idx) HIP_TRY(h, hipFree(h->d_delta_idx));
+        if (h->pin_delta) HIP_TRY(h, hipHostFree(h->pin_delta));
+        if (h->pin_delta_idx) HIP_TRY(h, hipHostFree(h->pin_delta_idx));
+        h->d_delta = nullptr; h->d_delta_idx = nullptr; h->pin_delta = nullptr; h->pin_delta_idx = nullptr;
+        h->delta_cap_groups = 0;
+        HIP_TRY(h, hipMalloc((void **)&h->d_delta, groups * 64 * sizeof(dsm_surfel)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_delta_idx, groups * sizeof(int32_t)));
+        HIP_TRY(h, hipHostMalloc((void **)&h->pin_delta, groups * 64 * sizeof(dsm_surfel), hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void **)&h->pin_delta_idx, groups * sizeof(int32_t), hipHostMallocDefault));
+        h->delta_cap_groups = (int)groups;
     }
     return DSM_OK;
 }
 
-// frame into slot 0 without a host wait: rows -> page-locked staging -> device staging -> pitched slot (repack kernel)
+int sync_and_fetch_counts(dsm_handle *h);
+
+// Drop-in calls, the way back: what the frame changed of the map, into the shadow and into the caller's array.  Before the
+// frame the three were equal over the caller's n records (dropin_map_in); the kernels flagged every 64-record group they wrote
+// (DeviceCtx::grp_dirty).  dropin_delta_begin goes between the upload of the map and the frame's map stages, dropin_delta_end
+// behind them: it packs the flagged groups on the device, brings them over in one transfer -- sized by the previous call's
+// count, so that one host wait serves the sizes and the records alike; a second transfer follows only if more changed --
+// and patches both host copies.  A frame that changed most of the map takes the plain full download.
+int dropin_delta_begin(dsm_handle *h) {
+    if (!h->dirty_flags_clean) { // flags left by frames of the resident / batched kind
+        HIP_TRY(h, hipMemsetAsync(h->hc.grp_dirty, 0, (size_t)h->hc.cap / 64 + 1, h->stream));
+        h->dirty_flags_clean = true;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars + 56, 0, 4, h->stream));
+    return DSM_OK;
+}
+// m_bound: the largest size the map can have now.  Synchronises; on return h_scalars[0..2] hold the frame's counts.
+int dropin_delta_end(dsm_handle *h, dsm_surfel *local, int32_t cap_local, int m_bound, int *m_out) {
+    const hipError_t e = launch_delta_pack(h->hc, h->d_delta, h->d_delta_idx, h->d_scalars + 56, h->delta_cap_groups, m_bound, h->stream);
+    if (e != hipSuccess) return fail(h, DSM_E_HIP, "delta pack: %s", hipGetErrorString(e));
+    int guess = h->dropin_last_groups + h->dropin_last_groups / 4 + 8;
+    if (guess > h->delta_cap_groups) guess = h->delta_cap_groups;
+    HIP_TRY(h, hipMemcpyAsync(h->pin_delta_idx, h->d_delta_idx, (size_t)guess * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_delta, h->d_delta, (size_t)guess * 64 * sizeof(dsm_surfel), hipMemcpyDeviceToHost, h->stream));
+    h->shadow_n = -1;
+    const auto t_w0 = std::chrono::steady_clock::now();
+    if (int rc = sync_and_fetch_counts(h)) return rc;
+    const auto t_w1 = std::chrono::steady_clock::now();
+    h->dropin_us[2] += std::chrono::duration<double, std::micro>(t_w1 - t_w0).count();
+    struct PatchTimer { // (everything from here on is bringing the rest over and patching)
+        dsm_handle *h;
+        std::chrono::steady_clock::time_point t;
+        ~PatchTimer() { h->dropin_us[3] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); }
+    } patch_timer{h, t_w1};
+    const int m = h->h_scalars[0], n_grp = h->h_scalars[4];
+    *m_out = m;
+    h->dropin_calls++;
+    h->dropin_last_groups = n_grp;
+    if (m > cap_local) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap_local);
+    if ((size_t)m > h->pin_map_cap) return fail(h, DSM_E_STATE, "drop-in shadow smaller than the map");
+    if ((int64_t)n_grp * 64 * 10 > (int64_t)m * 6 || n_grp > h->delta_cap_groups) { // most of it changed: everything, in one piece
+        if (m) {
+            HIP_TRY(h, hipMemcpy(h->pin_map, h->hc.local, (size_t)m * sizeof(dsm_surfel), hipMemcpyDeviceToHost));
+            par_copy(h, local, h->pin_map, (size_t)m * sizeof(dsm_surfel));
+        }
+        return DSM_OK;
+    }
+    if (n_grp > guess) { // more changed than the last call suggested: the rest
+        HIP_TRY(h, hipMemcpyAsync(h->pin_delta_idx + guess, h->d_delta_idx + guess, (size_t)(n_grp - guess) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->pin_delta + (size_t)guess * 64, h->d_delta + (size_t)guess * 64, (size_t)(n_grp - guess) * 64 * sizeof(dsm_surfel),
+                                  hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->dropin_delta_calls++;
+    h->dropin_delta_groups += n_grp;
+    constexpr int kPatch = 128; // groups per task
+    h->pool->run((n_grp + kPatch - 1) / kPatch, [&](int t) {
+        for (int i = t * kPatch; i < n_grp && i < (t + 1) * kPatch; i++) {
+            const int g = h->pin_delta_idx[i];
+            const int recs = m - g * 64 < 64 ? m - g * 64 : 64;
+            if (recs <= 0) continue;
+            const dsm_surfel *src = h->pin_delta + (size_t)i * 64;
+            memcpy(h->pin_map + (size_t)g * 64, src, (size_t)recs * sizeof(dsm_surfel));
+            memcpy(local + (size_t)g * 64, src, (size_t)recs * sizeof(dsm_surfel));
+        }
+    });
+    return DSM_OK;
+}
+
+// frame into slot 0 without a host wait: the caller's rows go into page-locked staging laid out like the slot itself (the
+// slot's pitch; the host threads copy row by row anyway), then one transfer per plane straight into the slot
 int dropin_frame(dsm_handle *h, const uint8_t *image, size_t img_step, const float *depth, size_t depth_step) {
     if (!image || !depth) return fail(h, DSM_E_INVALID, "null image/depth");
-    const int w = h->hc.w, hh = h->hc.h;
+    const int w = h->hc.w, hh = h->hc.h, pitch = h->hc.pitch;
     if (img_step < (size_t)w || depth_step < (size_t)w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
-    const size_t n = (size_t)w * hh;
+    const size_t plane = (size_t)pitch * hh;
     uint8_t *pi = h->pin_frame;
-    uint8_t *pd = h->pin_frame + n;
-    h->pool->run(hh, [&](int y) {
-        memcpy(pi + (size_t)y * w, image + (size_t)y * img_step, (size_t)w);
-        memcpy(pd + (size_t)y * w * 4, (const uint8_t *)depth + (size_t)y * depth_step, (size_t)w * 4);
+    uint8_t *pd = h->pin_frame + plane;
+    constexpr int kRows = 16; // rows per task
+    h->pool->run((hh + kRows - 1) / kRows, [&](int t) {
+        for (int y = t * kRows; y < hh && y < (t + 1) * kRows; y++) {
+            memcpy(pi + (size_t)y * pitch, image + (size_t)y * img_step, (size_t)w);
+            memcpy(pd + (size_t)y * pitch * 4, (const uint8_t *)depth + (size_t)y * depth_step, (size_t)w * 4);
+        }
     });
-    HIP_TRY(h, hipMemcpyAsync(h->d_stage_img, pi, n, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_stage_depth, pd, n * 4, hipMemcpyHostToDevice, h->stream));
-    const hipError_t e = launch_repack((uint8_t *)h->hc.img_base, (float *)h->hc.depth_base, h->hc.pitch, h->d_stage_img, h->d_stage_depth, w, hh,
-                                       h->stream);
-    if (e != hipSuccess) return fail(h, DSM_E_HIP, "frame repack: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync((uint8_t *)h->hc.img_base, pi, plane, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync((float *)h->hc.depth_base, pd, plane * 4, hipMemcpyHostToDevice, h->stream));
     return DSM_OK;
 }
 
@@ -729,10 +831,13 @@ int check_status(dsm_handle *h) {
 }
 
 int sync_and_fetch_counts(dsm_handle *h) {
-    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[0], h->hc.n_local, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[1], h->hc.n_new, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[2], h->hc.status, 4, hipMemcpyDeviceToHost, h->stream));
+    // ONE transfer for the whole scalar block (a call into the runtime costs more than the 256 bytes)
+    HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[64], h->d_scalars, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->h_scalars[0] = h->h_scalars[64 + 8];
+    h->h_scalars[1] = h->h_scalars[64 + 24];
+    h->h_scalars[2] = h->h_scalars[64 + 48];
+    h->h_scalars[4] = h->h_scalars[64 + 56];
     h->frames_done = h->frames_submitted;
     h->map_upper = h->h_scalars[0];
     h->fence_pending = false; // nothing is in flight any more
@@ -919,6 +1024,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     }
     CREATE_TRY(dev_alloc(h, &c.local, (size_t)c.cap));
     CREATE_TRY(dev_alloc(h, &c.fresh, (size_t)c.n_seed));
+    CREATE_TRY(dev_alloc(h, &c.grp_dirty, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.hole_mask, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.wave_prefix, (size_t)c.cap / 64 + 1));
     CREATE_TRY(dev_alloc(h, &c.holes, (size_t)c.cap));
@@ -926,6 +1032,7 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
     CREATE_TRY(dev_alloc(h, &c.hole_chunk, (size_t)c.n_hole_chunk + 2));
     int32_t *scalars = nullptr; // shared: n_local, n_local_next, n_new, n_holes, status
     CREATE_TRY(dev_alloc(h, &scalars, 64));
+    h->d_scalars = scalars;
     c.n_local = scalars + 8; c.n_local_next = scalars + 16; c.n_new = scalars + 24;
     c.n_holes = scalars + 32; c.status = scalars + 48;
     CREATE_TRY(dev_alloc(h, &h->d_params, (size_t)kParamRing));
@@ -998,8 +1105,8 @@ int dsm_create(const dsm_config *cfg, dsm_handle **out) {
         CREATE_TRY(hipStreamSynchronize(h->stream)); // tmp is on the stack
     }
     CREATE_TRY(hipHostMalloc((void **)&h->h_params, sizeof(FrameParams) * kParamRing, hipHostMallocDefault));
-    CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 256, hipHostMallocDefault));
-    memset(h->h_scalars, 0, 256);
+    CREATE_TRY(hipHostMalloc((void **)&h->h_scalars, 512, hipHostMallocDefault));
+    memset(h->h_scalars, 0, 512);
     for (int i = 0; i <= kNumStages + 1; i++) CREATE_TRY(hipEventCreate(&h->ev[i]));
     h->have_events = true;
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -1062,6 +1169,10 @@ void dsm_destroy(dsm_handle *h) {
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
     if (h->pin_frame) (void)hipHostFree(h->pin_frame);
     if (h->pin_map) (void)hipHostFree(h->pin_map);
+    if (h->pin_delta) (void)hipHostFree(h->pin_delta);
+    if (h->pin_delta_idx) (void)hipHostFree(h->pin_delta_idx);
+    if (h->d_delta) (void)hipFree(h->d_delta);
+    if (h->d_delta_idx) (void)hipFree(h->d_delta_idx);
     delete h->pool;
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1108,15 +1219,15 @@ int dsm_fuse_initialize_map_inv(dsm_handle *h, int reference_frame_index, const 
     if ((rc = stage_params(h, 0, reference_frame_index, pose16, inv_pose16))) return rc;
     if ((rc = submit_part(h, false, false))) return rc;            // superpixels run while the host compares / copies the map
     if ((rc = dropin_map_in(h, local, n_local))) return rc;
+    if ((rc = dropin_delta_begin(h))) return rc;
     if ((rc = submit_part(h, false, true))) return rc;
-    // results into the shadow: the updated map, then (behind it) the new surfels
-    const size_t b_map = (size_t)n_local * sizeof(dsm_surfel);
-    if (n_local) HIP_TRY(h, hipMemcpyAsync(h->pin_map, h->hc.local, b_map, hipMemcpyDeviceToHost, h->stream));
+    // results: the new surfels behind the shadow's map part, and of the map what the frame changed (no compaction: the
+    // fused and the deleted surfels)
     HIP_TRY(h, hipMemcpyAsync(h->pin_map + n_local, h->hc.fresh, (size_t)S * sizeof(dsm_surfel), hipMemcpyDeviceToHost, h->stream));
-    if ((rc = sync_and_fetch_counts(h))) { h->shadow_n = -1; return rc; }
+    int m = 0;
+    if ((rc = dropin_delta_end(h, local, n_local, n_local, &m))) { h->shadow_n = -1; return rc; }
     const int k = h->h_scalars[1];
     *n_new = k;
-    if (n_local) par_copy(h, local, h->pin_map, b_map);
     h->shadow_n = n_local; // no compaction: the device map keeps its size
     if (k > new_cap) return fail(h, DSM_E_CAPACITY, "%d new surfels exceed new_cap %d", k, new_cap);
     if (k) memcpy(new_out, h->pin_map + n_local, (size_t)k * sizeof(dsm_surfel));
@@ -1142,19 +1253,22 @@ int dsm_fuse_map_inv(dsm_handle *h, int reference_frame_index, const uint8_t *im
     size_t n_back = (size_t)n_in + (size_t)S;
     if (n_back > (size_t)h->hc.cap) n_back = (size_t)h->hc.cap;
     if ((rc = dropin_reserve(h, n_back > (size_t)n_in ? n_back : (size_t)n_in))) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
     if ((rc = dropin_frame(h, image, img_step, depth, depth_step))) return rc;
     if ((rc = stage_params(h, 0, reference_frame_index, pose16, inv_pose16))) return rc;
     if ((rc = submit_part(h, true, false))) return rc;             // superpixels run while the host compares / copies the map
+    const auto t1 = std::chrono::steady_clock::now();
     if ((rc = dropin_map_in(h, local, n_in))) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+    h->dropin_us[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    h->dropin_us[1] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+    if ((rc = dropin_delta_begin(h))) return rc;
     if ((rc = submit_part(h, true, true))) return rc;
-    // the whole possible extent comes back in one copy enqueued behind the frame: no wait for the new size first
-    if (n_back) HIP_TRY(h, hipMemcpyAsync(h->pin_map, h->hc.local, n_back * sizeof(dsm_surfel), hipMemcpyDeviceToHost, h->stream));
-    h->shadow_n = -1;
-    if ((rc = sync_and_fetch_counts(h))) return rc;
-    const int m = h->h_scalars[0];
+    // of the map, what the frame changed comes back: the surfels it fused or deleted, the slots it refilled or moved, what it
+    // appended (dropin_delta_end)
+    int m = 0;
+    if ((rc = dropin_delta_end(h, local, cap, (int)n_back, &m))) return rc;
     *n_new = h->h_scalars[1];
-    if (m > cap) return fail(h, DSM_E_CAPACITY, "%d surfels exceed the caller's capacity %d", m, cap);
-    if (m) par_copy(h, local, h->pin_map, (size_t)m * sizeof(dsm_surfel));
     *n_local = m;
     h->shadow_n = m;
     return DSM_OK;
@@ -1765,6 +1879,14 @@ int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap) {
     return DSM_OK;
 }
 
+// debug tap: the drop-in calls' delta downloads so far
+int dsm_debug_dropin_stats(dsm_handle *h, int64_t *out /* 8 */) {
+    if (!h || !out) return DSM_E_INVALID;
+    out[0] = h->dropin_calls; out[1] = h->dropin_delta_calls; out[2] = h->dropin_delta_groups; out[3] = h->dropin_last_groups;
+    for (int i = 0; i < 4; i++) out[4 + i] = (int64_t)h->dropin_us[i];
+    return DSM_OK;
+}
+
 // debug tap: how many seeds the latest frame's lane-per-seed kernels handed on to their second tiers
 int dsm_debug_tier_counts(dsm_handle *h, int32_t *out /* 8 */) {
     if (!h || !out) return DSM_E_INVALID;
@@ -1963,6 +2085,7 @@ int batch_advance(dsm_batch *b, int m) {
     for (dsm_handle *h : b->hs) {
         h->batch_order_ev = b->ev_out; // (waited for when the handle's stream is next used)
         h->shadow_n = -1;
+        h->dirty_flags_clean = false;
         h->reads_untracked = true;
         h->frames_submitted += m;
         const int64_t up = (int64_t)h->map_upper + (int64_t)m * h->hc.n_seed;

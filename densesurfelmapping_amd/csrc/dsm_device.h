@@ -106,6 +106,10 @@ struct DeviceCtx {
     int32_t *n_local;
     int32_t *n_local_next;
     int32_t *n_new;
+    // [cap/64 + 1] group g = records 64g .. 64g+63: a record of it was written since the flags were last cleared (k_fuse_surfels:
+    // a wave stores its 64 records back only if one changed; k_frame_tail: refills, moves, appended surfels).  The drop-in call
+    // downloads the flagged groups only (k_delta_pack clears them); flags left by other frames are cleared before it looks
+    uint8_t *grp_dirty;
     uint64_t *hole_mask;  // [cap/64] bit i of word v: surfel 64v+i has update_times == 0
     int32_t *wave_prefix; // [cap/64] exclusive prefix of popcounts
     int32_t *holes;       // [cap] ascending indices of deleted slots
@@ -161,5 +165,8 @@ hipError_t launch_repack(uint8_t *d_img, float *d_depth, int pitch, const uint8_
 hipError_t launch_extract_marked(const DeviceCtx &ctx, dsm_surfel *out, int cap, float4 *cloud_out, hipStream_t st);
 hipError_t launch_extract(const DeviceCtx &ctx, int key, dsm_surfel *out, int cap, int n_upper, hipStream_t st);
 hipError_t launch_append_count(const DeviceCtx &ctx, int n, hipStream_t st);
+// the flagged 64-record groups of the map (DeviceCtx::grp_dirty) packed into `buf` ([cap_groups][64] records) with their
+// group numbers in `idx`; count[0] = how many there are (may exceed cap_groups: those are not packed), flags cleared
+hipError_t launch_delta_pack(const DeviceCtx &ctx, dsm_surfel *buf, int32_t *idx, int32_t *count, int cap_groups, int n_upper, hipStream_t st);
 
 } // namespace dsm

@@ -152,6 +152,7 @@ __device__ __forceinline__ DeviceCtx load_ctx(const DeviceCtx *src) {
     DSM_G(n_local);
     DSM_G(n_local_next);
     DSM_G(n_new);
+    DSM_G(grp_dirty);
     DSM_G(hole_mask);
     DSM_G(wave_prefix);
     DSM_G(holes);

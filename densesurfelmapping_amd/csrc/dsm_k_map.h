@@ -175,7 +175,10 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_fuse_surfels(cons
             if (big_map && m) atomicAdd(&c->hole_chunk[base / (64 * kTailChunkWords)], __popcll(m)); // (deletions are rare)
         }
         wave_lds_sync();
-        if (__ballot(changed) != 0) records_from_lds<64>(c->local + base, s_w, cnt, lane); // (stored back only if a surfel of the 64 changed)
+        if (__ballot(changed) != 0) { // (stored back only if a surfel of the 64 changed)
+            records_from_lds<64>(c->local + base, s_w, cnt, lane);
+            if (lane == 0) c->grp_dirty[base >> 6] = 1;
+        }
         wave_lds_sync();
     }
 }
@@ -342,12 +345,16 @@ __device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c, in
         }
         for (int j = tid; j < K; j += nthr) {
             const int tgt = j < k ? c->holes[k - 1 - j] : M + (j - k);
-            if (tgt < c->cap) local[tgt] = rec[idx[j]];
+            if (tgt < c->cap) { local[tgt] = rec[idx[j]]; c->grp_dirty[tgt >> 6] = 1; }
         }
     } else {
         const int r = k - K, cut = M - r;
         new_m = cut;
-        for (int j = tid; j < K; j += nthr) local[c->holes[k - 1 - j]] = rec[idx[j]];
+        for (int j = tid; j < K; j += nthr) {
+            const int tgt = c->holes[k - 1 - j];
+            local[tgt] = rec[idx[j]];
+            c->grp_dirty[tgt >> 6] = 1;
+        }
         for (int i = tid; i < r; i += nthr) {
             const int tgt = c->holes[r - 1 - i];
             if (tgt >= cut) continue;
@@ -355,6 +362,7 @@ __device__ __forceinline__ void tail_compact(const DeviceCtx *__restrict__ c, in
             bool hole;
             while ((hole = is_hole(c, src, rank)) && rank < r) src = M - 1 - (r - 1 - rank);
             local[tgt] = hole ? rec[idx[k - 1 - rank]] : local[src];
+            c->grp_dirty[tgt >> 6] = 1;
         }
     }
     if (tid == 0) c->n_local_next[0] = new_m;
@@ -462,7 +470,7 @@ __device__ __forceinline__ bool frame_tail_fast(const DeviceCtx *__restrict__ c,
         }
         for (int j = tid; j < K; j += 1024) {
             const int tgt = j < k ? s_refill[j] : M + (j - k);
-            if (tgt < c->cap) c->local[tgt] = rec[s_idx[j]];
+            if (tgt < c->cap) { c->local[tgt] = rec[s_idx[j]]; c->grp_dirty[tgt >> 6] = 1; }
         }
         if (tid == 0) {
             c->n_holes[0] = k;
@@ -739,6 +747,50 @@ hipError_t launch_extract(const DeviceCtx &d, int key, dsm_surfel *out, int cap,
 }
 hipError_t launch_append_count(const DeviceCtx &d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_append, dim3(1), dim3(64), 0, st, d, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ delta download (drop-in calls)
+// SurfelMap::fuse_map hands its vector to every frame and gets it back (SM.cpp:1066-1073); a frame changes the surfels it
+// fuses, deletes, refills and appends -- in a growing map a fraction of the array.  k_delta_pack gathers the 64-record groups
+// that k_fuse_surfels / k_frame_tail flagged (DeviceCtx::grp_dirty) into one contiguous block with their group numbers, so that
+// one transfer of what changed replaces the transfer of everything; the flags are cleared on the way.  A thread per group
+// looks at its flag; a wave then copies its flagged groups one after the other, 176 16-byte vectors each.
+__global__ __launch_bounds__(256) void k_delta_pack(const DeviceCtx ctx, dsm_surfel *__restrict__ buf, int32_t *__restrict__ idx,
+                                                    int32_t *__restrict__ count, int cap_groups) {
+    const DeviceCtx *__restrict__ c = &ctx;
+    const int M = c->n_local[0], n_grp = (M + 63) >> 6, lane = lane_id();
+    const int n_flag = c->cap / 64 + 1;
+    for (int g0 = (blockIdx.x * 256 + (int)threadIdx.x - lane); g0 < n_flag; g0 += gridDim.x * 256) {
+        const int g = g0 + lane;
+        bool dirty = false;
+        if (g < n_flag && c->grp_dirty[g]) {
+            c->grp_dirty[g] = 0;
+            dirty = g < n_grp; // (a group beyond the map's new end: cut off by the compaction)
+        }
+        const unsigned long long m = __ballot(dirty);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (dirty && base + rank_below(m) < cap_groups) idx[base + rank_below(m)] = g;
+        int slot = base;
+        for (unsigned long long w = m; w; w &= w - 1, slot++) {
+            if (slot >= cap_groups) break;
+            const int gg = g0 + (__ffsll((long long)w) - 1);
+            const int recs = M - gg * 64 < 64 ? M - gg * 64 : 64;
+            const int n_vec = (recs * (int)sizeof(dsm_surfel) + 15) >> 4; // (a group starts 16-byte aligned: 64 x 44 = 176 x 16)
+            const float4 *src = reinterpret_cast<const float4 *>(c->local + (size_t)gg * 64);
+            float4 *dst = reinterpret_cast<float4 *>(buf + (size_t)slot * 64);
+            for (int v = lane; v < n_vec; v += 64) dst[v] = src[v];
+        }
+    }
+}
+hipError_t launch_delta_pack(const DeviceCtx &d, dsm_surfel *buf, int32_t *idx, int32_t *count, int cap_groups, int n_upper, hipStream_t st) {
+    (void)n_upper; // (every flag is looked at: a frame that shrank the map leaves flags beyond its new end, which are dropped)
+    int blocks = (d.cap / 64 + 1 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_delta_pack, dim3(blocks), dim3(256), 0, st, d, buf, idx, count, cap_groups);
     return hipGetLastError();
 }
 

@@ -326,6 +326,13 @@ int dsm_debug_set_fit_small_cap(dsm_handle *h, int32_t cap);
  * ran the wave-per-seed kernels.  Synchronises. */
 int dsm_debug_tier_counts(dsm_handle *h, int32_t *out /* 8 */);
 
+/* debug tap: the drop-in calls (dsm_fuse_map / dsm_fuse_initialize_map) bring back only the 64-record groups of the map a frame
+ * changed: out[0] = drop-in calls so far, out[1] = of them, calls that took the delta path (the others changed most of the map
+ * and took one full download), out[2] = groups those brought back in all, out[3] = groups of the latest call; out[4..7] = host
+ * microseconds spent so far in dsm_fuse_map calls on: staging the frame and launching its superpixel stages | comparing the
+ * caller's array with the shadow (and uploading it if it differs) | waiting for the GPU | fetching and patching what changed. */
+int dsm_debug_dropin_stats(dsm_handle *h, int64_t *out /* 8 */);
+
 /* ---- per-kernel timing (hip events on the handle's stream) ----------------------------- */
 #define DSM_MAX_STAGES 32
 typedef struct dsm_stage_times {

@@ -112,6 +112,57 @@ def test_dropin_shadow_detects_caller_edits(mods):
     ff.close()
 
 
+def test_dropin_delta_download(mods):
+    """The drop-in calls bring back only what a frame changed of the map (round 6: the 64-record groups k_fuse_surfels and
+    k_frame_tail flag, packed on the device, one transfer, patched into the shadow and the caller's array; SM.cpp:1066-1073
+    hands the same vector to every frame).  90 frames at 1226x370 on the caller's own array, the map growing to 60 k surfels
+    with pruning and both compaction branches on the way: after EVERY call the caller's array is the oracle's, byte for byte;
+    most calls take the delta path and bring back a fraction of the map.  Then the same through the reference node's own entry
+    point (dsm_fuse_initialize_map: no compaction, the caller's loop refills and appends -- SM.cpp:1077-1109 -- so every call sees
+    an edited array), and with resident frames in between, which leave flags of their own behind."""
+    api, synth, ob = mods
+    cam, scene = synth.KITTI_1226, synth.Scene(seed=3)
+    frames = list(synth.sequence(cam, scene, 90))
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=2, surfel_capacity=1 << 18)
+    orc = ob.PortOracle(cam)
+    buf = np.zeros(1 << 17, api.SURFEL_DTYPE)
+    n, lo = 0, np.zeros(0, ob.SURFEL_DTYPE)
+    shrank = grew = False
+    for t, img, dep, pose, ref in frames:
+        before = n
+        n, k = ff.fuse_map_inplace(ref, img, dep, pose, buf, n)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        assert k == ko and n == len(lo), f"frame {t}"
+        assert fields_equal(buf[:n], lo.astype(api.SURFEL_DTYPE)) == [], f"frame {t}"
+        shrank |= n < before
+        grew |= n > before
+        if t == 40:  # resident frames in between: the map moves on behind the shadow's back, their flags stay behind
+            ff.frame_upload(0, frames[41][1], frames[41][2])
+            ff.fuse_frame_resident(0, frames[41][4], frames[41][3])
+            ff.synchronize()
+            ff.map_upload(buf[:n])  # (back to the caller's state: the flags the resident frame set are stale now)
+    st = ff.debug_dropin_stats()
+    assert st["calls"] == 90 and st["delta_calls"] >= 60, st
+    groups_in_map = (n + 63) // 64
+    assert st["delta_groups"] / st["delta_calls"] < 0.6 * groups_in_map, (st, groups_in_map)
+    assert grew and n > 40000
+    print("drop-in delta download:", st, "groups in the final map:", groups_in_map)
+    ff.close()
+    # ---- the reference node's own path: fuse_initialize_map + the caller's compaction loop (here: the oracle's fuse_map, which
+    # IS that loop) -- the array the next call sees was edited by the caller every time
+    ff = api.FusionFunctions.from_camera(cam, surfel_capacity=1 << 18)
+    lo = np.zeros(0, ob.SURFEL_DTYPE)
+    for t, img, dep, pose, ref in frames[:40]:
+        g_local, g_new = ff.fuse_initialize_map(ref, img, dep, pose, lo)
+        o_local, o_new = orc.fuse_initialize_map(ref, img, dep, pose, lo)
+        assert fields_equal(g_local, o_local.astype(api.SURFEL_DTYPE)) == [], f"frame {t}: local"
+        assert fields_equal(g_new, o_new.astype(api.SURFEL_DTYPE)) == [], f"frame {t}: new"
+        lo, _ = orc.fuse_map(ref, img, dep, pose, lo)
+    st = ff.debug_dropin_stats()
+    assert st["calls"] == 40 and st["delta_calls"] >= 20, st
+    ff.close()
+
+
 def test_resident_replay_kitti(mods):
     """BASELINE config 2 shape: 1226x370, map and frames resident in HBM, one graph replay per frame."""
     api, synth, ob = mods
