@@ -406,8 +406,8 @@ def open_group(args, world, rank, local_rank):
 def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
     """`--workload sharded`: BASELINE configs[2] as the north star states it.  One synthetic KITTI-shaped sequence of
     world x (W + K) x F frames is cut into `world` contiguous subsequences (replay.shard_subsequences); rank r streams ITS
-    subsequence from page-locked host memory through ONE handle (replay.HipEngine: pipeline depth 24, chunks of 48 frames on
-    the device's upload stream beside the kernels of the chunk before, three groups of frame slots in turn), keyframe indices
+    subsequence from page-locked host memory through ONE handle (replay.HipEngine: pipeline depth 24, every group of eight frames
+    uploaded on the stream that runs its superpixel stages, right in front of them: dsm_replay_enqueue_host), keyframe indices
     restarting at its first frame, the map resident; the final clouds are merged by one all-gather of the counts and one of the
     padded clouds (RCCL).  A step = F frames of every rank's subsequence; the warm-up steps are replayed first (same engine,
     same map), the K timed steps between two barriers as ONE streamed replay.  Rank 0's final map is checked against the CPU
@@ -427,6 +427,7 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
         dist.barrier()  # rank 0 renders the scene's period (cached in /tmp), the others read it
     t_r = time.perf_counter()
     src = rp.SyntheticSource(world * per_rank, camera="KITTI_1226", seed=12345, prerender=True)
+    src.prepare(a, b)  # (poses up front, as a log's are)
     render_s = time.perf_counter() - t_r
     if world > 1 and rank == 0:
         dist.barrier()
@@ -479,7 +480,7 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
            "config": {"workload": "BASELINE configs[2]: one KITTI-shaped 1226x370 sequence split into one contiguous subsequence per GPU, every rank's frames "
                                   "streamed from page-locked host memory through one handle (frame groups), map resident, RCCL all-gather of the final clouds",
                       "frames_per_rank_per_step": F, "frames_per_rank": per_rank, "timed_frames_per_rank": K * F, "shards": [list(s_) for s_ in shards],
-                      "pipeline_depth": args.pipeline_depth or 24, "chunk_frames": 48, "frame_slot_groups": rp.HipEngine.GROUPS,
+                      "pipeline_depth": args.pipeline_depth or 24, "chunk_frames": 48, "host_blocks": rp.HipEngine.BLOCKS,
                       "host_to_device_GBps_per_rank": round(st["frames"] * st["bytes_per_frame"] / st["seconds"] / 1e9, 2),
                       "frames_already_page_locked": st["zero_copy"], "timed_seconds": round(dt, 4), "host_render_seconds": round(render_s, 1),
                       "final_surfels_all_ranks": int(sum(counts)),
@@ -1283,13 +1284,14 @@ def main():
         from densesurfelmapping_amd import replay as rp
         n_w, n_t = 480, 2880
         res = {}
-        for label in ("page_locked_source", "prefetch_thread_copy"):
+        for label in ("page_locked_source_first_engine", "page_locked_source", "prefetch_thread_copy"):
             src = rp.SyntheticSource(n_w + n_t, camera="KITTI_1226", seed=12345, prerender=True)
             if label == "prefetch_thread_copy":
                 src.pinned_run = None  # (the generic path: frames() only)
+            src.prepare(0, n_w + n_t)  # (poses up front, as a log's are)
             eng = rp.HipEngine(cam, device=device, capacity=capacity, pipeline_depth=24, chunk=48)
             eng.replay(src, 0, n_w)
-            eng.replay(src, n_w, n_w + n_t)
+            eng.replay(src, n_w, n_w + n_t, origin=0)
             st = eng.stats
             res[label] = {"frames_per_s": round(st["frames"] / st["seconds"], 1),
                           "host_to_device_GBps": round(st["frames"] * st["bytes_per_frame"] / st["seconds"] / 1e9, 2),
@@ -1298,8 +1300,11 @@ def main():
             src.close()
         out["sharded_replay"] = {"value": res["page_locked_source"]["frames_per_s"], "unit": "frames/s per rank", "frames": n_t,
                                  "pipeline_depth": 24, "chunk_frames": 48, **res,
-                                 "note": "one rank of BASELINE configs[2] (replay.HipEngine.replay): dsm_frames_upload_async of chunk k+1, then "
-                                         "dsm_replay_enqueue of chunk k; parity per shard: tests/test_gpu_parity.py::test_sharded_replay_*"}
+                                 "note": "one rank of BASELINE configs[2] (replay.HipEngine.replay): dsm_replay_enqueue_host per chunk of 48 frames -- every group "
+                                         "of eight frames uploaded on the stream that runs its superpixel stages, in front of them; the FIRST streaming engine "
+                                         "of a process runs below the ones after it for a few thousand frames (one-time costs of the runtime: "
+                                         "profiles/r06_streaming.md), so the same replay is measured on a first engine and on a second, `value` = the second; "
+                                         "parity per shard: tests/test_gpu_parity.py::test_sharded_replay_*, test_replay_engine_streams_in_chunks"}
 
     if leg_on("kitti_like") and args.mode == "batched":
         # The reference's REAL input distribution through the timed form: the same batched replay on frames

@@ -50,7 +50,7 @@ ABI_SYMBOLS = (
     "dsm_map_warp", "dsm_warp_grouped_device", "dsm_map_extract", "dsm_map_append",
     "dsm_store_deactivate", "dsm_store_activate", "dsm_store_erase", "dsm_store_warp", "dsm_store_size",
     "dsm_store_download",
-    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_frame_pitch", "dsm_frame_upload_async", "dsm_frames_upload_async", "dsm_frame_uploads_wait", "dsm_fuse_frame_resident", "dsm_replay_enqueue",
+    "dsm_frame_upload", "dsm_frame_upload_device", "dsm_frame_pitch", "dsm_frame_upload_async", "dsm_frames_upload_async", "dsm_frame_uploads_wait", "dsm_fuse_frame_resident", "dsm_replay_enqueue", "dsm_replay_enqueue_host", "dsm_replay_wait",
     "dsm_synchronize", "dsm_last_new_count", "dsm_stream",
     "dsm_batch_create", "dsm_batch_destroy", "dsm_batch_last_error", "dsm_batch_replay_enqueue", "dsm_batch_synchronize",
     "dsm_batch_replay_timed",
@@ -113,6 +113,8 @@ def load_library():
     lib.dsm_fuse_map_inv.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_int32, _vp]
     lib.dsm_fuse_frame_resident_inv.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.dsm_replay_enqueue_inv.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp]
+    lib.dsm_replay_enqueue_host.argtypes = [_vp, C.c_int32, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+    lib.dsm_replay_wait.argtypes = [_vp, C.c_int32]
     lib.dsm_batch_replay_enqueue_inv.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp]
     lib.dsm_map_upload.argtypes = [_vp, _vp, C.c_int32]
     lib.dsm_map_size.argtypes = [_vp, _vp]
@@ -428,6 +430,28 @@ class FusionFunctions:
             inv_poses_cm = np.ascontiguousarray(inv_poses_cm, np.float32).reshape(len(slots), 16)
             inv = _ptr(inv_poses_cm)
         self._check(self._lib.dsm_replay_enqueue_inv(self._h, len(slots), _ptr(slots), _ptr(ref_idx), _ptr(poses_cm), inv))
+
+    def replay_enqueue_host(self, pinned, first, ref_idx, poses_cm, inv_poses_cm=None):
+        """frames first .. first+n-1 of a PinnedFrames block (n = len(ref_idx)) fused in order, each group of frames uploaded on
+        the stream that runs its superpixel stages, right in front of them (include/dsm.h, dsm_replay_enqueue_host); the block's
+        frames may be rewritten once replay_wait says the call is done"""
+        n = len(ref_idx)
+        assert 0 <= first and first + n <= pinned.n and (pinned.h, pinned.w, pinned.pitch) == (self.height, self.width, self.frame_pitch())
+        if n == 0:
+            return
+        img, dep = pinned.image(first), pinned.depth(first)
+        inv = None
+        if inv_poses_cm is not None:
+            inv_poses_cm = np.ascontiguousarray(inv_poses_cm, np.float32).reshape(n, 16)
+            inv = _ptr(inv_poses_cm)
+        ref_idx = np.ascontiguousarray(ref_idx, np.int32)
+        poses_cm = np.ascontiguousarray(poses_cm, np.float32).reshape(n, 16)
+        self._check(self._lib.dsm_replay_enqueue_host(self._h, n, _ptr(img), img.strides[0], pinned.pitch * pinned.h, _ptr(dep), dep.strides[0],
+                                                      pinned.pitch * pinned.h * 4, _ptr(ref_idx), _ptr(poses_cm), inv))
+
+    def replay_wait(self, calls_back=0):
+        """host wait until the frames of the replay_enqueue_host call `calls_back` calls ago have been fused"""
+        self._check(self._lib.dsm_replay_wait(self._h, int(calls_back)))
 
     def synchronize(self):
         self._check(self._lib.dsm_synchronize(self._h))

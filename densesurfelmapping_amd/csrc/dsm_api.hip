@@ -156,10 +156,15 @@ struct dsm_handle {
     DeviceCtx *d_pipe_ctxs = nullptr;                 // [n_pipe] the pipelines' contexts, for the batched kernels
     hipGraphExec_t g_group[4] = {nullptr, nullptr, nullptr, nullptr}; // superpixel stages of pipelines [kG, (k+1)G)
     hipGraphExec_t g_group_map[4] = {nullptr, nullptr, nullptr, nullptr}; // their fuse + tail stages, frame after frame
+    // ... and the same with k_frame_tail's workgroups for a large map, captured beside the first (while the replay warms up) if
+    // the handle's capacity allows the map to get there: map_grows then only swaps them in (a capture in the middle of a
+    // replay is 50 ms of host time during which the GPU runs dry)
+    hipGraphExec_t g_group_map_large[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t params_pending = 0; // bit p: pipeline p has not yet waited for the latest params upload; kSerialBit: the map stream (serial / drop-in calls)
     hipStream_t copy_stream = nullptr; // per-frame params go up here, so that they never queue behind the map stream
     hipEvent_t ev_params = nullptr;
     std::vector<void *> allocs; // every hipMalloc of this handle
+    std::vector<hipGraphExec_t> retired; // graphs replaced while possibly in flight (map_grows): destroyed at the next synchronisation point
     FrameParams *h_params = nullptr; // pinned staging ring
     int32_t *h_scalars = nullptr;    // pinned: [0] n_local, [1] n_new, [2] status, [3] scratch, [4] delta groups; [64..127] the device's scalar block as it came
     int32_t *d_scalars = nullptr;    // the device's scalar block (64 ints: n_local @8, n_local_next @16, n_new @24, n_holes @32, status @48, delta count @56)
@@ -212,6 +217,10 @@ struct dsm_handle {
     int rd_n = 0;
     bool reads_untracked = true;
     int up_which = -1; // which of the device's upload streams this handle's uploads take (dealt out at its first upload)
+    // dsm_replay_enqueue_host: an event behind each of the last kHostRing calls (dsm_replay_wait)
+    static constexpr int kHostRing = 8;
+    hipEvent_t host_ring[kHostRing] = {};
+    int64_t host_calls = 0;
     bool touched = true; // a per-handle call may have put work on the handle's stream since a batch last ordered itself behind it
     // the other way round: the handle's stream has to come behind the batch it last advanced with (its frames read and
     // write the handle's buffers) -- the wait is put onto the stream when the stream is next used (bind_device), not after
@@ -324,8 +333,10 @@ int stage_params(dsm_handle *h, int slot, int ref_idx, const float *pose16, cons
 
 // stage the params of up to n consecutive frames with one host-to-device copy; returns how many
 // were staged (limited by the ring's wrap-around point)
+// defer_copy: the entries are only written to the page-locked ring; whoever submits the frames copies them to the device on the
+// stream that runs them (dsm_replay_enqueue_host: no copy stream, no event in front of a frame group)
 int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t *ref_idx, const float *poses16, const float *inv_poses16, int *staged,
-                       hipStream_t batch_stream = nullptr) {
+                       hipStream_t batch_stream = nullptr, bool defer_copy = false) {
     const int ring = (int)(h->frames_submitted % kParamRing);
     int m = n < kParamRing - ring ? n : kParamRing - ring;
     if (m > kParamRing / 2) m = kParamRing / 2;
@@ -341,7 +352,8 @@ int stage_params_batch(dsm_handle *h, int n, const int32_t *slots, const int32_t
         fp.slot = slots[i];
         fp.pad[0] = fp.pad[1] = 0;
     }
-    if (h->n_pipe == 1) {
+    if (defer_copy) {
+    } else if (h->n_pipe == 1) {
         // (a batch copies them on ITS stream, in order with the kernels that read them: see batch_stage)
         HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)m, hipMemcpyHostToDevice, batch_stream ? batch_stream : h->stream));
     } else {
@@ -393,16 +405,26 @@ int map_grows(dsm_handle *h, int frames) {
     if (h->tail_large) return DSM_OK;
     if ((int64_t)h->map_upper + (int64_t)(frames - 1) * h->hc.n_seed <= (int64_t)kTailFastWords * 64) return DSM_OK;
     h->tail_large = true;
-    HIP_TRY(h, hipStreamSynchronize(h->stream)); // (the graphs may be in flight)
-    for (int i = 0; i < 4; i++)
-        if (h->g_group_map[i]) { (void)hipGraphExecDestroy(h->g_group_map[i]); h->g_group_map[i] = nullptr; }
+    // The graphs may be in flight: they are set aside, not destroyed -- and nothing is waited for (until round 6 the map stream
+    // was drained here: 50 ms in the middle of a streamed replay, a quarter of a 3 000-frame run) -- and go at the handle's next
+    // synchronisation point (retire_graphs).
+    auto retire = [&](hipGraphExec_t &g) { if (g) { h->retired.push_back(g); g = nullptr; } };
+    for (int i = 0; i < 4; i++) {
+        retire(h->g_group_map[i]);
+        h->g_group_map[i] = h->g_group_map_large[i]; // (captured beside the small-map form, if at all)
+        h->g_group_map_large[i] = nullptr;
+    }
     for (int p = 0; p < kMaxPipes; p++)
         for (int i = 0; i < 2; i++) {
-            dsm_handle::Pipe &pp = h->pipe[p];
-            if (pp.g_map[i]) { (void)hipGraphExecDestroy(pp.g_map[i]); pp.g_map[i] = nullptr; }
-            if (pp.g_all[i]) { (void)hipGraphExecDestroy(pp.g_all[i]); pp.g_all[i] = nullptr; }
+            retire(h->pipe[p].g_map[i]);
+            retire(h->pipe[p].g_all[i]);
         }
     return DSM_OK;
+}
+// after the handle's streams have been waited for: the graphs map_grows set aside
+void retire_graphs(dsm_handle *h) {
+    for (hipGraphExec_t g : h->retired) (void)hipGraphExecDestroy(g);
+    h->retired.clear();
 }
 
 // grow-only device scratch of the handle (tail copy of dsm_store_erase, argument blocks of the warps)
@@ -454,9 +476,54 @@ int capture(dsm_handle *h, const DeviceCtx &ctx, bool with_compaction, int lo, i
     return DSM_OK;
 }
 
+// Frames that come with the enqueue call (dsm_replay_enqueue_host): `n` frames in page-locked host memory, frame i at
+// image + i * img_frame_step / depth + i * depth_frame_step.  They go up ON THE STREAM THAT RUNS THEIR SUPERPIXEL STAGES, right
+// in front of them, into the frame slots of the pipelines that take them (slot = pipeline): no upload stream, no event between
+// an upload and its consumer, and a transfer holds up only the hardware queue of the work that waits for it anyway.
+struct HostFrames {
+    const uint8_t *image = nullptr;
+    const float *depth = nullptr;
+    size_t img_step = 0, img_frame_step = 0, depth_step = 0, depth_frame_step = 0;
+};
+// frames [first, first + n) of `f0` into the frame slots slot_base + first ..., on `st`
+int upload_host_frames(dsm_handle *h, const HostFrames &f0, int slot_base, int first, int n, hipStream_t st) {
+    constexpr int which = 3;
+    if (n <= 0) return DSM_OK;
+    HostFrames f = f0;
+    f.image = f0.image + (size_t)first * f0.img_frame_step;
+    f.depth = (const float *)((const char *)f0.depth + (size_t)first * f0.depth_frame_step);
+    const int slot0 = slot_base + first;
+    const int w = h->hc.w, hh = h->hc.h, pitch = h->hc.pitch;
+    uint8_t *di = (uint8_t *)h->hc.img_base + (int64_t)slot0 * h->hc.slot_elems;
+    float *dd = (float *)h->hc.depth_base + (int64_t)slot0 * h->hc.slot_elems;
+    const size_t plane = (size_t)pitch * (size_t)hh;
+    const bool img_flat = f.img_step == (size_t)pitch, dep_flat = f.depth_step == (size_t)pitch * 4;
+    if (!(which & 1)) {
+    } else if (img_flat && (n == 1 || f.img_frame_step == plane)) {
+        HIP_TRY(h, hipMemcpyAsync(di, f.image, plane * (size_t)(n - 1) + (size_t)pitch * (size_t)(hh - 1) + (size_t)w, hipMemcpyHostToDevice, st));
+    } else {
+        for (int i = 0; i < n; i++) {
+            const uint8_t *src = f.image + (size_t)i * f.img_frame_step;
+            if (img_flat) HIP_TRY(h, hipMemcpyAsync(di + (size_t)i * plane, src, (size_t)pitch * (size_t)(hh - 1) + (size_t)w, hipMemcpyHostToDevice, st));
+            else HIP_TRY(h, hipMemcpy2DAsync(di + (size_t)i * plane, (size_t)pitch, src, f.img_step, (size_t)w, (size_t)hh, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (!(which & 2)) {
+    } else if (dep_flat && (n == 1 || f.depth_frame_step == plane * 4)) {
+        HIP_TRY(h, hipMemcpyAsync(dd, f.depth, (plane * (size_t)(n - 1) + (size_t)pitch * (size_t)(hh - 1) + (size_t)w) * 4, hipMemcpyHostToDevice, st));
+    } else {
+        for (int i = 0; i < n; i++) {
+            const float *src = (const float *)((const char *)f.depth + (size_t)i * f.depth_frame_step);
+            if (dep_flat) HIP_TRY(h, hipMemcpyAsync(dd + (size_t)i * plane, src, ((size_t)pitch * (size_t)(hh - 1) + (size_t)w) * 4, hipMemcpyHostToDevice, st));
+            else HIP_TRY(h, hipMemcpy2DAsync(dd + (size_t)i * plane, (size_t)pitch * 4, src, f.depth_step, (size_t)w * 4, (size_t)hh, hipMemcpyHostToDevice, st));
+        }
+    }
+    return DSM_OK;
+}
+
 // enqueue the kernels of one frame whose params were staged by stage_params: superpixel stages on the
-// frame's pipeline stream, fuse + tail on the map stream
-int submit_frame(dsm_handle *h, bool with_compaction) {
+// frame's pipeline stream, fuse + tail on the map stream.  host: the frame itself, to go up in front of them (slot = pipeline)
+int submit_frame(dsm_handle *h, bool with_compaction, const HostFrames *host = nullptr) {
     h->shadow_n = -1;
     h->dirty_flags_clean = false;
     h->reads_untracked = true; // (dsm_replay_enqueue, which lists what it reads, puts the flag back)
@@ -467,6 +534,11 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
     const int wc = with_compaction ? 1 : 0;
     if (h->n_pipe == 1) { // everything on the map stream, one graph
         if (int rc = wait_uploads(h, h->stream, kSerialBit)) return rc;
+        if (host) {
+            const int ring = (int)(h->frames_submitted % kParamRing);
+            HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams), hipMemcpyHostToDevice, h->stream));
+            if (int rc = upload_host_frames(h, *host, 0, 0, 1, h->stream)) return rc;
+        }
         if (eager) {
             hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, h->stream, nullptr);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -484,6 +556,11 @@ int submit_frame(dsm_handle *h, bool with_compaction) {
             h->params_pending &= ~(1ull << p);
         }
         if (int rc = wait_uploads(h, pp.stream, 1ull << p)) return rc;
+        if (host) { // (behind ev_free: the frame that last read slot p has been fused)
+            const int ring = (int)(h->frames_submitted % kParamRing);
+            HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams), hipMemcpyHostToDevice, pp.stream));
+            if (int rc = upload_host_frames(h, *host, p, 0, 1, pp.stream)) return rc;
+        }
         if (eager) {
             hipError_t e = launch_frame(pp.ctx, h->map_upper, h->map_upper, with_compaction, pp.stream, nullptr, 0, kLastSuperpixelStage);
             if (e != hipSuccess) return fail(h, DSM_E_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -526,7 +603,7 @@ int group_size(const dsm_handle *h) { return (h->n_pipe == 12 || h->n_pipe == 24
 bool group_path(const dsm_handle *h) {
     return h->n_pipe >= 4 && h->d_pipe_ctxs && !(h->cfg.flags & DSM_FLAG_NO_GRAPH);
 }
-int submit_group(dsm_handle *h) {
+int submit_group(dsm_handle *h, const HostFrames *host = nullptr) {
     h->shadow_n = -1;
     h->dirty_flags_clean = false;
     h->reads_untracked = true;
@@ -556,6 +633,14 @@ int submit_group(dsm_handle *h) {
     // (only `lead` reads these frames' slots before the map stream does -- which waits for lead.ev_sp below -- and only the
     // lead stream's bit is cleared: a later frame-by-frame submit on another of these pipelines waits for itself)
     if (int rc = wait_uploads(h, lead.stream, 1ull << half)) return rc;
+    // the G frames themselves, if they came with the call: slots p0 .. p0 + G - 1, behind the wait for the frames that read them last
+    if (host) {
+        // ... and their parameters in front of them, on the same stream (the ring entries of G consecutive frames are adjacent: the
+        // ring's length is a multiple of every group size)
+        const int ring = (int)(h->frames_submitted % kParamRing);
+        HIP_TRY(h, hipMemcpyAsync(h->d_params + ring, h->h_params + ring, sizeof(FrameParams) * (size_t)G, hipMemcpyHostToDevice, lead.stream));
+        if (int rc = upload_host_frames(h, *host, p0, 0, G, lead.stream)) return rc;
+    }
     if (!h->g_group[half]) {
         const std::string err = capture_graph([&](hipStream_t st) {
             return launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, st, nullptr, 0, kLastSuperpixelStage, h->d_pipe_ctxs + p0, G);
@@ -575,6 +660,15 @@ int submit_group(dsm_handle *h) {
             return le;
         }, &h->g_group_map[half]);
         if (!err.empty()) return fail(h, DSM_E_HIP, "%s", err.c_str());
+        if (!h->tail_large && h->hc.cap > kTailFastWords * 64 && !h->g_group_map_large[half]) { // the large-map form, for later
+            const std::string err2 = capture_graph([&](hipStream_t st) {
+                hipError_t le = hipSuccess;
+                for (int j = 0; j < G && le == hipSuccess; j++)
+                    le = launch_frame(h->pipe[p0 + j].ctx, fuse_grid_bound(h), h->hc.cap, true, st, nullptr, kLastSuperpixelStage + 1, kNumStages - 1);
+                return le;
+            }, &h->g_group_map_large[half]);
+            if (!err2.empty()) return fail(h, DSM_E_HIP, "%s", err2.c_str());
+        }
     }
     HIP_TRY(h, hipGraphLaunch(h->g_group_map[half], h->stream));
     // ONE event for the group (every record is a marker packet on the map stream, the serial spine of a sequence)
@@ -712,6 +806,7 @@ int dropin_reserve(dsm_handle *h, size_t map_records) {
 }
 
 int sync_and_fetch_counts(dsm_handle *h);
+void retire_graphs(dsm_handle *h);
 
 // Drop-in calls, the way back: what the frame changed of the map, into the shadow and into the caller's array.  Before the
 // frame the three were equal over the caller's n records (dropin_map_in); the kernels flagged every 64-record group they wrote
@@ -834,6 +929,7 @@ int sync_and_fetch_counts(dsm_handle *h) {
     // ONE transfer for the whole scalar block (a call into the runtime costs more than the 256 bytes)
     HIP_TRY(h, hipMemcpyAsync(&h->h_scalars[64], h->d_scalars, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    retire_graphs(h); // (they ran on this stream)
     h->h_scalars[0] = h->h_scalars[64 + 8];
     h->h_scalars[1] = h->h_scalars[64 + 24];
     h->h_scalars[2] = h->h_scalars[64 + 48];
@@ -1130,9 +1226,11 @@ void dsm_destroy(dsm_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream && h->batch_order_ev) (void)hipStreamWaitEvent(h->stream, h->batch_order_ev, 0); // (a batch may still be working on this handle's buffers)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    retire_graphs(h);
     for (int i = 0; i < 4; i++) {
         if (h->g_group[i]) (void)hipGraphExecDestroy(h->g_group[i]);
         if (h->g_group_map[i]) (void)hipGraphExecDestroy(h->g_group_map[i]);
+        if (h->g_group_map_large[i]) (void)hipGraphExecDestroy(h->g_group_map_large[i]);
     }
     for (int p = 0; p < kMaxPipes; p++) {
         dsm_handle::Pipe &pp = h->pipe[p];
@@ -1158,6 +1256,8 @@ void dsm_destroy(dsm_handle *h) {
     }
     for (int i = 0; i < dsm_handle::kRdRing; i++)
         if (h->rd_ring[i].ev) (void)hipEventDestroy(h->rd_ring[i].ev);
+    for (int i = 0; i < dsm_handle::kHostRing; i++)
+        if (h->host_ring[i]) (void)hipEventDestroy(h->host_ring[i]);
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     if (h->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(h->ev[i]);
@@ -1686,6 +1786,61 @@ int dsm_replay_enqueue(dsm_handle *h, int32_t n, const int32_t *slots, const int
     return dsm_replay_enqueue_inv(h, n, slots, ref_idx, poses16, nullptr);
 }
 
+int dsm_replay_enqueue_host(dsm_handle *h, int32_t n, const uint8_t *image, size_t img_step, size_t img_frame_step, const float *depth,
+                            size_t depth_step, size_t depth_frame_step, const int32_t *ref_idx, const float *poses16, const float *inv_poses16) {
+    if (!h) return DSM_E_INVALID;
+    if (n < 0 || (n > 0 && (!image || !depth || !ref_idx || !poses16))) return fail(h, DSM_E_INVALID, "null/negative argument");
+    if (!h->map_valid) return fail(h, DSM_E_STATE, "no resident map: call dsm_map_upload first (n may be 0)");
+    if (h->hc.n_slots < h->n_pipe) return fail(h, DSM_E_INVALID, "dsm_replay_enqueue_host keeps a frame in the slot of its pipeline: %d frame slots for pipeline_depth %d", h->hc.n_slots, h->n_pipe);
+    if (img_step < (size_t)h->hc.w || depth_step < (size_t)h->hc.w * 4) return fail(h, DSM_E_INVALID, "row step smaller than a row");
+    if (n > 1 && (img_frame_step < img_step * (size_t)h->hc.h || depth_frame_step < depth_step * (size_t)h->hc.h)) return fail(h, DSM_E_INVALID, "frame step smaller than a frame");
+    int rc = bind_device(h);
+    if (rc) return rc;
+    // the frames read -- and overwrite -- the slots of the pipelines they run on: uploads of the asynchronous kind that
+    // follow wait for the whole stream
+    std::vector<int32_t> slots((size_t)(n > 0 ? n : 0));
+    for (int i = 0; i < n; i++) slots[(size_t)i] = (int32_t)((h->frames_submitted + i) % h->n_pipe);
+    HostFrames hf;
+    hf.img_step = img_step; hf.img_frame_step = img_frame_step; hf.depth_step = depth_step; hf.depth_frame_step = depth_frame_step;
+    for (int i = 0; i < n;) {
+        int m = 0;
+        if ((rc = stage_params_batch(h, n - i, slots.data() + i, ref_idx + i, poses16 + 16 * (size_t)i,
+                                     inv_poses16 ? inv_poses16 + 16 * (size_t)i : nullptr, &m, nullptr, true))) return rc;
+        for (int j = 0; j < m;) {
+            const int G = group_size(h);
+            hf.image = image + (size_t)(i + j) * img_frame_step;
+            hf.depth = (const float *)((const char *)depth + (size_t)(i + j) * depth_frame_step);
+            if (group_path(h) && m - j >= G && h->frames_submitted % G == 0) {
+                if ((rc = submit_group(h, &hf))) return rc;
+                j += G;
+            } else {
+                if ((rc = submit_frame(h, true, &hf))) return rc;
+                j++;
+            }
+        }
+        i += m;
+    }
+    if (n) {
+        h->fence_pending = true;
+        h->reads_untracked = true;
+        // an event behind this call's frames, for dsm_replay_wait (the page-locked frames may be rewritten once it has fired)
+        hipEvent_t &ev = h->host_ring[h->host_calls % dsm_handle::kHostRing];
+        if (!ev) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(ev, h->stream));
+        h->host_calls++;
+    }
+    return DSM_OK;
+}
+
+int dsm_replay_wait(dsm_handle *h, int32_t calls_back) {
+    if (!h) return DSM_E_INVALID;
+    if (calls_back < 0 || calls_back >= dsm_handle::kHostRing) return fail(h, DSM_E_INVALID, "calls_back %d out of range [0, %d)", calls_back, dsm_handle::kHostRing);
+    if (h->host_calls <= calls_back) return DSM_OK; // no such call yet: nothing to wait for
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->host_ring[(h->host_calls - 1 - calls_back) % dsm_handle::kHostRing]));
+    return DSM_OK;
+}
+
 int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx, const float *poses16,
                            const float *inv_poses16) {
     if (!h) return DSM_E_INVALID;
@@ -1990,6 +2145,7 @@ hipStream_t batch_stream_take(int device) {
 struct dsm_batch {
     std::vector<dsm_handle *> hs;
     std::vector<uint64_t> gens; // the handles' generations at dsm_batch_create
+    std::vector<hipGraphExec_t> retired; // graphs replaced while possibly in flight (batch_map_grows)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false; // false: one of the device's reserved batch streams
@@ -2073,9 +2229,8 @@ int batch_map_grows(dsm_batch *b, int m) {
     for (const dsm_handle *h : b->hs) large = large || (int64_t)h->map_upper + (int64_t)(m - 1) * h->hc.n_seed > (int64_t)kTailFastWords * 64;
     if (!large) return DSM_OK;
     b->tail_large = true;
-    if (b->graph) {
-        BHIP_TRY(b, hipStreamSynchronize(b->stream));
-        (void)hipGraphExecDestroy(b->graph);
+    if (b->graph) { // (possibly in flight: set aside without a wait, destroyed at the batch's next synchronisation point)
+        b->retired.push_back(b->graph);
         b->graph = nullptr;
     }
     return DSM_OK;
@@ -2168,6 +2323,7 @@ void dsm_batch_destroy(dsm_batch *b) {
         }
     }
     if (b->graph) (void)hipGraphExecDestroy(b->graph);
+    for (hipGraphExec_t g : b->retired) (void)hipGraphExecDestroy(g); // (the batch's stream was waited for above)
     if (b->ev_out) (void)hipEventDestroy(b->ev_out);
     if (b->have_events)
         for (int i = 0; i <= kNumStages + 1; i++) (void)hipEventDestroy(b->ev[i]);
@@ -2216,6 +2372,9 @@ int dsm_batch_synchronize(dsm_batch *b) {
         if (!rc) rc = sync_and_fetch_counts(b->hs[j]);
         if (rc) return bfail(b, rc, "handle %zu: %s", j, b->hs[j]->err.c_str());
     }
+    // (the handles' streams came behind the batch's and have been waited for: a graph set aside by batch_map_grows is done)
+    for (hipGraphExec_t g : b->retired) (void)hipGraphExecDestroy(g);
+    b->retired.clear();
     return DSM_OK;
 }
 

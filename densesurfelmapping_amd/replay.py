@@ -91,6 +91,7 @@ class SyntheticSource:
         self.n_frames = n_frames
         self._period = None
         self._pinned = None
+        self._poses = {}
         if prerender:
             per = self.scene.frames_per_period
             self._period = synth.render_many([(self.cam, self.scene, i) for i in range(min(per, n_frames))])
@@ -101,13 +102,21 @@ class SyntheticSource:
         if self._period is not None:
             for t in range(a, b):
                 image, depth = self._period[t % len(self._period)]
-                yield image, depth, self.scene.pose(t)
+                yield image, depth, self.pose(t)
             return
         for t, image, depth, pose, _ in synth.sequence(self.cam, self.scene, b - a, start=a):
             yield image, depth, pose
 
     def pose(self, t):
-        return self.scene.pose(t)
+        p = self._poses.get(t)
+        return p if p is not None else self.scene.pose(t)
+
+    def prepare(self, a, b):
+        """the poses of frames a .. b-1, worked out once (a log's poses are an array read up front: kitti.read_poses; here they
+        are trigonometry per frame, which a replay at twenty thousand frames a second would spend a third of its time on)"""
+        for t in range(a, b):
+            if t not in self._poses:
+                self._poses[t] = self.scene.pose(t)
 
     def pinned_run(self, api, t, n_max):
         """frames t .. t+n-1 (n <= n_max) as a run of a page-locked block in slot layout: (block, first, n), or None when
@@ -185,23 +194,25 @@ class KittiSource:
 class HipEngine:
     """One handle of the HIP engine (include/dsm.h) with a resident map, driven the way the library is fastest for ONE
     sequence: frame groups (pipeline depth 24: the superpixel stages of eight consecutive frames per batched launch, fuse
-    + compaction in frame order on the map stream) and frames streamed from page-locked host memory in chunks --
-    dsm_frames_upload_async for chunk k+1, then dsm_replay_enqueue for chunk k, so that the transfer of one chunk runs
-    beside the kernels of the one before.  THREE groups of `chunk` frame slots take turns: the upload of chunk k+1 overwrites
-    the slots of chunk k-2, which finished long ago -- the library orders an upload behind the newest enqueue call that
-    reads its slots (include/dsm.h), and a wait that is already satisfied does not stall the hardware queue the upload
-    stream shares with the handle's pipeline streams (with two groups it waits for chunk k-1: 11 k instead of 13-14 k frames/s).  Frames reach the page-locked blocks on a
-    prefetch thread (decode / render / copy) unless the source already keeps them there (`pinned_run`).  `fuse` is the
-    frame-at-a-time form of the same thing (SurfelMap::fuse_map, surfel_map.cpp:1060-1113).  There is no other engine in this package:
-    without a gfx950 device the constructor raises (DSM_E_NO_DEVICE)."""
+    + compaction in frame order on the map stream) and the frames coming WITH the enqueue call from page-locked host memory
+    (dsm_replay_enqueue_host, round 6): every group of eight frames goes up on the stream that runs its superpixel stages,
+    right in front of them -- no upload stream, no event between a transfer and its consumer; the transfer of one group runs
+    beside the kernels of the two before it, each on a hardware queue of its own.  (Until round 6 the frames went ahead on
+    the device's upload stream, ordered by events against the pipelines that share its hardware queue: 11-14 k frames/s,
+    +- 20 % with the queue the stream happened to be given.)  Frames reach page-locked blocks on a prefetch thread (decode /
+    render / copy; FOUR blocks of `chunk` frames in turn: one being filled, three in flight) unless the source already keeps
+    them there (`pinned_run`).  `fuse` is the frame-at-a-time form of the same thing (SurfelMap::fuse_map,
+    surfel_map.cpp:1060-1113).  There is no other engine in this package: without a gfx950 device the constructor raises
+    (DSM_E_NO_DEVICE)."""
 
-    GROUPS = 3  # groups of frame slots used in turn
+    BLOCKS = 4  # page-locked blocks of `chunk` frames the prefetch thread fills in turn (one being filled, up to three in flight)
 
     def __init__(self, cam, device=0, capacity=0, pipeline_depth=24, chunk=48):
         from . import api
         self._api = api
         self.chunk = max(1, int(chunk))
-        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=self.GROUPS * self.chunk, surfel_capacity=capacity,
+        self.depth = int(pipeline_depth) if pipeline_depth else 4
+        self.ff = api.FusionFunctions.from_camera(cam, device=device, frame_slots=max(self.depth, 2), surfel_capacity=capacity,
                                                   pipeline_depth=pipeline_depth)
         self.ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
         self.n = 0
@@ -209,7 +220,7 @@ class HipEngine:
         self.stats = {}
 
     def fuse(self, image, depth, pose, ref_idx):  # one frame: blocking upload into a slot, one enqueue
-        slot = self.n % (self.GROUPS * self.chunk)
+        slot = self.n % max(self.depth, 2)
         self.ff.frame_upload(slot, image, depth)
         self.ff.fuse_frame_resident(slot, ref_idx, pose)
         self.n += 1
@@ -226,76 +237,63 @@ class HipEngine:
         chunks = [(a + c0, min(C, n_total - c0)) for c0 in range(0, n_total, C)]  # (first frame, frames)
         zero_copy = getattr(source, "pinned_run", None) is not None and source.pinned_run(api, a, 1) is not None
         ready = queue.Queue()
-        free = threading.Semaphore(3)
+        free = threading.Semaphore(self.BLOCKS)
         stop = threading.Event()
         if not zero_copy and self._pins is None:
-            self._pins = [api.PinnedFrames(ff, C) for _ in range(3)]
+            self._pins = [api.PinnedFrames(ff, C) for _ in range(self.BLOCKS)]
 
-        def produce():  # decode / render / copy chunk k into page-locked block k mod 3, as soon as that block is free
+        def produce():  # decode / render / copy chunk k into page-locked block k mod BLOCKS, as soon as that block is free
+            from concurrent.futures import ThreadPoolExecutor
             try:
-                for k, (t0, n) in enumerate(chunks):
-                    free.acquire()
-                    if stop.is_set():
-                        return
-                    pf = self._pins[k % 3]
-                    poses = []
-                    for i, (image, depth, pose) in enumerate(source.frames(t0, t0 + n)):
-                        pf.set(i, image, depth)
-                        poses.append(pose)
-                    ready.put((k, poses, None))
+                with ThreadPoolExecutor(2) as copiers:  # (numpy's copies drop the GIL: two of them move twice the bytes)
+                    for k, (t0, n) in enumerate(chunks):
+                        free.acquire()
+                        if stop.is_set():
+                            return
+                        pf = self._pins[k % self.BLOCKS]
+                        poses, jobs = [], []
+                        for i, (image, depth, pose) in enumerate(source.frames(t0, t0 + n)):
+                            jobs.append(copiers.submit(pf.set, i, image, depth))
+                            poses.append(pose)
+                        for j in jobs:
+                            j.result()
+                        ready.put((k, poses, None))
                 ready.put(None)
             except BaseException as e:  # noqa: BLE001 -- handed to the consumer
                 ready.put((None, None, e))
-
-        def send(k, half):  # chunk k -> slot group `half`
-            t0, n = chunks[k]
-            if zero_copy:
-                i = 0
-                while i < n:  # runs of the source's page-locked block (a run ends where its period does)
-                    pf, first, m = source.pinned_run(api, t0 + i, n - i)
-                    ff.frames_upload_async(half * C + i, pf, first, m)
-                    i += m
-            else:
-                ff.frames_upload_async(half * C, self._pins[k % 3], 0, n)
 
         th = None
         if not zero_copy:
             th = threading.Thread(target=produce, daemon=True)
             th.start()
         t_start = time.perf_counter()
-        poses_of = {}
-
-        def take(k):  # wait until chunk k's frames are in page-locked memory; their poses
-            if zero_copy:
-                t0, n = chunks[k]
-                poses_of[k] = [source.pose(t) for t in range(t0, t0 + n)]
-                return
-            item = ready.get()
-            if item is None or item[2] is not None:
-                raise item[2] if item else RuntimeError("frame source ended early")
-            poses_of[item[0]] = item[1]
-
         try:
-            if chunks:
-                take(0)
-                send(0, 0)
             for k, (t0, n) in enumerate(chunks):
-                if k + 1 < len(chunks):
-                    take(k + 1)
-                    send(k + 1, (k + 1) % self.GROUPS)  # BEFORE chunk k is enqueued; ordered behind chunk k - 2, whose slots it overwrites
-                half = k % self.GROUPS
-                slots = [half * C + i for i in range(n)]
-                refs = [(t0 - origin + i) // keyframe_every for i in range(n)]
-                ff.replay_enqueue(*ff.pack_replay(slots, refs, np.stack(poses_of.pop(k))))
-                if not zero_copy:
-                    # page-locked blocks may be refilled once their transfers have landed: the newest upload is chunk
-                    # k + 1's, behind chunk k - 1's kernels -- the device still holds chunk k's while the host waits
-                    ff.frame_uploads_wait()
-                    free.release()
+                refs = np.array([(t0 - origin + i) // keyframe_every for i in range(n)], np.int32)
+                if zero_copy:
+                    i = 0
+                    while i < n:  # runs of the source's page-locked block (a run ends where its period does)
+                        pf, first, m = source.pinned_run(api, t0 + i, n - i)
+                        poses = np.stack([api.pose_to_colmajor(source.pose(t)) for t in range(t0 + i, t0 + i + m)])
+                        ff.replay_enqueue_host(pf, first, refs[i:i + m], poses)
+                        i += m
+                else:
+                    item = ready.get()
+                    if item is None or item[2] is not None:
+                        raise item[2] if item else RuntimeError("frame source ended early")
+                    assert item[0] == k
+                    poses = np.stack([api.pose_to_colmajor(p) for p in item[1]])
+                    ff.replay_enqueue_host(self._pins[k % self.BLOCKS], 0, refs, poses)
+                    if k >= self.BLOCKS - 1:
+                        # once chunk k - (BLOCKS - 1) has been fused its block may be refilled -- with chunk k + 1; the chunks
+                        # in between stay in flight
+                        ff.replay_wait(self.BLOCKS - 1)
+                        free.release()
             ff.synchronize()
         finally:
             stop.set()
-            free.release()
+            for _ in range(self.BLOCKS):
+                free.release()
             if th is not None:
                 th.join(timeout=60)
         self.n += n_total

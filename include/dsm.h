@@ -258,6 +258,20 @@ int dsm_fuse_frame_resident_inv(dsm_handle *h, int slot, int reference_frame_ind
                                 const float *inv_pose16);
 int dsm_replay_enqueue_inv(dsm_handle *h, int32_t n, const int32_t *slots, const int32_t *ref_idx,
                            const float *poses16, const float *inv_poses16);
+/* The same with the frames COMING WITH THE CALL (round 6): n frames in page-locked host memory (dsm_host_alloc), frame i at
+ * image + i * img_frame_step / depth + i * depth_frame_step, rows img_step / depth_step bytes apart (rows at the frame slots' own
+ * pitch -- dsm_frame_pitch elements -- and frames one slot apart go up as one transfer per plane and group of frames).  What a
+ * replay of a log does (the reference receives every frame through image_input / depth_input, surfel_map.cpp:83-101).  Each
+ * group of frames is uploaded ON THE STREAM THAT RUNS ITS SUPERPIXEL STAGES, right in front of them, into the frame slots of the
+ * pipelines that take it (frame f -> slot f mod pipeline_depth: the handle needs frame_slots >= pipeline_depth, and whatever
+ * those slots held is overwritten): no upload stream and no event between a transfer and its consumer, the transfer of one
+ * group runs beside the kernels of the groups before it, and nothing is waited for on the host.  The host memory of a call
+ * may be rewritten once dsm_replay_wait says the call's frames are done. */
+int dsm_replay_enqueue_host(dsm_handle *h, int32_t n, const uint8_t *image, size_t img_step, size_t img_frame_step, const float *depth,
+                            size_t depth_step, size_t depth_frame_step, const int32_t *ref_idx, const float *poses16,
+                            const float *inv_poses16 /* may be NULL */);
+/* host wait until the frames of the dsm_replay_enqueue_host call `calls_back` calls ago (0 = the latest; < 8) have been fused */
+int dsm_replay_wait(dsm_handle *h, int32_t calls_back);
 int dsm_synchronize(dsm_handle *h);
 /* number of new surfels created by the last completed frame; synchronises */
 int dsm_last_new_count(dsm_handle *h, int32_t *n_new);
