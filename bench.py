@@ -434,6 +434,10 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
     if spec:
         oracle_job = start_oracle_replays([spec])[0]
     cam = src.cam
+    if per_rank >= 96:  # the runtime's one-time costs (profiles/r06_streaming.md): a throw-away engine over the shard's first frames
+        pre = rp.HipEngine(cam, device=device, capacity=1 << 21, pipeline_depth=args.pipeline_depth or 24, chunk=48)
+        pre.replay(src, a, a + min(480, per_rank), origin=a)
+        pre.close()
     eng = rp.HipEngine(cam, device=device, capacity=1 << 21, pipeline_depth=args.pipeline_depth or 24, chunk=48)
     if W:
         eng.replay(src, a, a + W * F, origin=a)
