@@ -73,7 +73,8 @@ BATCHED_KERNELS_OF_STAGE = {
     "seed_points": ["k_pixel_normals<true>", "k_seed_stats<true>"],
     "seed_fit": ["k_seed_fit<true, 1>", "k_seed_fit<true, 2>", "k_seed_finish<true>"],
 }
-PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r05_pmc_traffic.json", "r05_pmc_traffic_batched.json", "r05_pmc_sq_batch8.md"
+PMC_TRAFFIC_SINGLE, PMC_TRAFFIC_BATCHED, PMC_SQ_BATCHED = "r06_pmc_traffic.json", "r06_pmc_traffic_batched.json", "r06_pmc_sq_batch32.md"
+PMC_SQ_LAUNCH = 32  # subsequences per launch of the SQ pass (the launches the timed region makes)
 DEFAULT_SUBSEQUENCES = 128  # batched mode: 4 batches of 32 (round 4; 32 in 4 batches of 8 until then)
 
 
@@ -99,9 +100,9 @@ def pmc_traffic(kernels, name, per_launch=None):
 
 def valu_issue(fps_per_gpu, clock_ghz=None):
     """The roof that binds the batched superpixel stages: VALU instruction issue.  Wave-instructions per frame from the
-    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 8 subsequences (profiles/r05_pmc_sq_batch8.md;
-    the counts are per launch, a frame launches the sweep kernels two or three times) against what 1 024 SIMDs issue at one
-    wave64 instruction per 4 cycles.  clock_ghz: the shader clock sampled during the timed region (2.4 GHz assumed when it
+    committed rocprofv3 --pmc SQ_INSTS_VALU pass over launches batched over 32 subsequences -- the launches the timed region
+    makes (profiles/r06_pmc_sq_batch32.md; the counts are per launch, a frame launches the sweep kernels two or three times)
+    -- against what 1 024 SIMDs issue at one wave64 instruction per 4 cycles.  clock_ghz: the shader clock sampled during the timed region (2.4 GHz assumed when it
     could not be read).  None when no pass is on file."""
     path = os.path.join(ROOT, "profiles", PMC_SQ_BATCHED)
     if not os.path.exists(path):
@@ -126,13 +127,13 @@ def valu_issue(fps_per_gpu, clock_ghz=None):
     launches = {k: 2 for k in twice}
     for k in ("k_commit_seeds<true>", "k_update_seeds<true>", "k_update_seeds_rest<true>"):
         launches[k] = 3
-    per_frame = sum(v * launches.get(k, 1) for k, v in per_launch.items() if not k.startswith("k_repack")) / 8.0
+    per_frame = sum(v * launches.get(k, 1) for k, v in per_launch.items() if not k.startswith("k_repack")) / float(PMC_SQ_LAUNCH)
     ghz = clock_ghz or 2.4
     peak = 256 * 4 * ghz * 1e9 / 4.0
     return {"valu_wave_insts_per_frame": round(per_frame), "peak_wave_insts_per_s": peak, "shader_clock_ghz": ghz,
             "shader_clock_source": "sampled during the timed region" if clock_ghz else "assumed (no clock sample available)",
             "frames_per_s_at_peak": round(peak / per_frame, 1), "frac": round(fps_per_gpu * per_frame / peak, 4),
-            "source": f"profiles/{PMC_SQ_BATCHED} (rocprofv3 --pmc SQ_INSTS_VALU, launches batched over 8 subsequences)",
+            "source": f"profiles/{PMC_SQ_BATCHED} (rocprofv3 --pmc SQ_INSTS_VALU, launches batched over {PMC_SQ_LAUNCH} subsequences)",
             "note": "every instruction priced at the fp32 rate; float<->double conversions issue at a quarter of it, and a wave "
                     "alone on its SIMD (the lane-per-seed kernels) issues one instruction per ~5.5 cycles, not 4"}
 
@@ -295,7 +296,7 @@ def cpu_baseline(cam, scene, rendered, period, lo, hi, budget_s=25.0):
                       f"per frame, {'10 std::threads per stage as in the reference' if kind == 'reference' else 'scalar C restatement'}"}
 
 
-PMC_MAP_8M = os.path.join(ROOT, "profiles", "r03_pmc_map_kernels_8m.json")
+PMC_MAP_8M = os.path.join(ROOT, "profiles", "r06_pmc_map_kernels_8m.json")
 
 
 def pmc_8m(kernel, us):
@@ -308,7 +309,7 @@ def pmc_8m(kernel, us):
     moved = row["fetch_bytes_corrected"] + row["write_bytes"]
     return {"traffic": {"read_bytes": row["fetch_bytes_corrected"], "write_bytes": row["write_bytes"], "l2_hit_rate": row["l2_hit_rate"],
                         "memory_side_GBps": round(moved / us / 1e3, 1), "of_achievable_6300_GBps": round(moved / us / 1e3 / 6300.0, 3),
-                        "source": "profiles/r03_pmc_map_kernels_8m.json (rocprofv3 --pmc, FETCH_SIZE corrected x2 for gfx950)"}}
+                        "source": "profiles/r06_pmc_map_kernels_8m.json (rocprofv3 --pmc on this round's build, FETCH_SIZE corrected x2 for gfx950)"}}
 
 
 def event_timer(torch, ff):
@@ -909,10 +910,18 @@ def main():
                                "frames_timed": int(nfb), "mean_live_surfels": round(mtb), "mean_new_surfels": round(kb, 1),
                                "timing": "HIP events between the kernels of an eager replay of ONE batch alone on the GPU, the empty-interval "
                                          "overhead (event_overhead_us) subtracted; `rocprofv3 --kernel-trace` of the same launches: "
-                                         "profiles/r05_kernel_trace_batch32x1.md; in the timed region four batches share the machine and a "
-                                         "launch takes longer (profiles/r05_kernel_trace_batch32x4_default.md)",
+                                         "profiles/r06_kernel_trace_batch32x1.md; in the timed region four batches share the machine and a "
+                                         "launch takes longer (profiles/r06_kernel_trace_batch32x4_default.md)",
                                "note": "the timed region launches every kernel once per batch of subsequences; roofline_single_launch is the "
                                        "same kernel launched for one subsequence"}
+            # the stage priced by ITS OWN compulsory bytes: the label planes here are 2 bytes per pixel (SURVEY.md's 9N counts the
+            # reference's 4-byte labels), so update_seeds must move 7N + 32S
+            if dom_fn == "k_update_seeds":
+                own = nb * (7 * n_pix + 32 * n_seed)
+                out["roofline"]["own_bytes"] = {"alg_bytes_per_launch": int(own), "achieved": round(own / (dom_usb * 1e-6) / 1e9, 1),
+                                                "frac": round(own / (dom_usb * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                                "traffic_over_own_bytes": round(traffic_b / own, 3) if traffic_b else None,
+                                                "note": "7N + 32S per frame: labels as this build stores them (2 B/pixel); `frac` above prices SURVEY.md's 9N + 32S"}
             # the WHOLE frame's algorithmic bytes over the whole frame's kernel time (the launch set
             # of one batch alone on the GPU), beside the dominant stage's own number -- and which roof actually binds
             b_alg_b = 9 * n_pix + 60 * n_seed + 88 * mtb + 44 * kb
