@@ -643,7 +643,7 @@ int submit_group(dsm_handle *h, const HostFrames *host = nullptr) {
     }
     if (!h->g_group[half]) {
         const std::string err = capture_graph([&](hipStream_t st) {
-            return launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, st, nullptr, 0, kLastSuperpixelStage, h->d_pipe_ctxs + p0, G);
+            return launch_frame(lead.ctx, fuse_grid_bound(h), tail_bound(h), true, st, nullptr, 0, kLastSuperpixelStage, h->d_pipe_ctxs + p0, G, 4);
         }, &h->g_group[half]);
         if (!err.empty()) return fail(h, DSM_E_HIP, "%s", err.c_str());
     }

@@ -148,9 +148,12 @@ extern const char *const kStageNames[kNumStages];
 // map_upper_bound sizes the grid-stride pass of k_fuse_surfels (any bound does, the loop covers the map); tail_map_bound
 // must be an upper bound of the map size whenever that exceeds kTailFastWords * 64 (it decides whether k_frame_tail gets
 // the workgroups that list a large map's holes), and may be 0 while the map is known to be smaller.
+// lanes_from: frames per launch from which the per-seed stages take their lane-per-seed forms (0 = the default for independent
+// handles, kLaneBatch; the frame groups of one sequence pass 4: with other groups' kernels sharing the GPU the lane forms win
+// from four frames on -- profiles/r06_wave_vs_lane.md)
 hipError_t launch_frame(const DeviceCtx &ctx, int map_upper_bound, int tail_map_bound, bool with_compaction,
                         hipStream_t stream, hipEvent_t *ev, int stage_lo = 0, int stage_hi = kNumStages - 1,
-                        const DeviceCtx *d_batch = nullptr, int n_batch = 1);
+                        const DeviceCtx *d_batch = nullptr, int n_batch = 1, int lanes_from = 0);
 
 struct WarpMat {
     float m[16]; // column-major 4x4

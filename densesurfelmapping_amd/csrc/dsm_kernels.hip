@@ -47,7 +47,7 @@ const char *const kStageNames[kNumStages] = {
 // d_batch != nullptr: the kernels take their context from d_batch[blockIdx.z], z < n_batch (handles of equal geometry
 // advancing in lockstep: one launch per kernel for all of them); hc is then any one of them (grid sizes).
 hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_bound, bool with_compaction,
-                        hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi, const DeviceCtx *d_batch, int n_batch) {
+                        hipStream_t st, hipEvent_t *ev, int stage_lo, int stage_hi, const DeviceCtx *d_batch, int n_batch, int lanes_from) {
     int stage = 0;
     hipError_t err = hipSuccess;
     const bool batched = d_batch != nullptr;
@@ -77,7 +77,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
     // Two forms of the per-seed stages (same results): a wave per seed where the launch's latency counts -- one handle, or
     // the few of a frame group -- and a lane per seed (and four pixels per thread in k_assign) where the instructions
     // issued count: launches batched over kLaneBatch handles or more.
-    const bool lanes = batched && n_batch >= kLaneBatch;
+    const bool lanes = batched && n_batch >= (lanes_from > 0 ? lanes_from : kLaneBatch);
     const dim3 g_tile1((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<1>::kH - 1) / AssignTile<1>::kH);
     const dim3 g_tile4((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<4>::kH - 1) / AssignTile<4>::kH);
     const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
