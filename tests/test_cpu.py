@@ -390,22 +390,24 @@ def test_bench_reads_the_committed_profiles():
     finally:
         sys.argv = argv
     b, src = bench.pmc_traffic("k_update_seeds", bench.PMC_TRAFFIC_SINGLE)
-    assert src == "r05_pmc_traffic.json" and 4_000_000 < b < 40_000_000
+    assert src == "r06_pmc_traffic.json" and 4_000_000 < b < 40_000_000
     # a batched stage may be several kernels (the lane-per-seed forms): their traffic is summed; the record is of the
     # launches the timed region makes (32 subsequences per launch) and is not used for any other batch size
     pair = bench.BATCHED_KERNELS_OF_STAGE["update_seeds_1"]
     b32, src32 = bench.pmc_traffic(pair, bench.PMC_TRAFFIC_BATCHED, 32)
-    assert src32 == "r05_pmc_traffic_batched.json" and 32 * 4_000_000 < b32 < 32 * 40_000_000
+    assert src32 == "r06_pmc_traffic_batched.json" and 32 * 4_000_000 < b32 < 32 * 40_000_000
     assert bench.pmc_traffic(pair, bench.PMC_TRAFFIC_BATCHED, 8) == (None, None)
     for stage, kernels in bench.BATCHED_KERNELS_OF_STAGE.items():
         assert bench.pmc_traffic(kernels, bench.PMC_TRAFFIC_BATCHED, 32)[0], (stage, kernels)
     v = bench.valu_issue(28000.0)
-    assert v and 8e6 < v["valu_wave_insts_per_frame"] < 18e6 and 0.3 < v["frac"] < 1.2, "VERDICT r02: <= 18 M wave-instructions per frame"
-    for name in ("r05_kernel_trace_batch8x1.md", "r05_kernel_trace_batch32x1.md", "r05_kernel_trace_batch32x4_default.md", "r05_kernel_trace_streams1.md",
-                 "r05_pmc_sq_batch8.md", "r05_pmc_sq_batch32.md", "r05_bench_default.json", "r05_bench_variance.md", "r05_ab_trip2.md", "r05_ceilings_trip3.md",
-                 "r03_eigen_exposure.md", "r02_relaxed_sums.md", "r02_issue_rates.md"):
+    assert v and 8e6 < v["valu_wave_insts_per_frame"] <= 10.8e6 and 0.3 < v["frac"] < 1.2, "VERDICT r05 next #4: <= 10.8 M wave-instructions per frame"
+    assert "batched over 32" in v["source"]  # (the launches the timed region makes, not a launch-of-8 pass scaled)
+    assert bench.pmc_8m("k_fuse_surfels", 200.0)["traffic"]["source"].startswith("profiles/r06_") and bench.pmc_8m("k_warp", 120.0)["traffic"]["read_bytes"] > 3e8
+    for name in ("r06_kernel_trace_batch8x1.md", "r06_kernel_trace_batch32x1.md", "r06_kernel_trace_batch32x4_default.md", "r06_kernel_trace_streams1.md",
+                 "r06_pmc_sq_batch8.md", "r06_pmc_sq_batch32.md", "r06_bench_default.json", "r06_bench_variance.md", "r06_streaming.md", "r06_wave_vs_lane.md",
+                 "r06_pmc_map_kernels_8m.md", "r06_open_picks.json", "r05_ceilings_trip3.md", "r03_eigen_exposure.md", "r02_relaxed_sums.md", "r02_issue_rates.md"):
         assert os.path.getsize(os.path.join(ROOT, "profiles", name)) > 200, name
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "verified_timed_region"):
         assert key in rec, key
@@ -414,8 +416,10 @@ def test_bench_reads_the_committed_profiles():
     # the record's run checked the maps the timed region itself left behind (hundreds of thousands of surfels each) against the oracle
     assert rec["verified"] is True and rec["verified_timed_region"] is True
     assert all(row["equal"] and row["surfels"] > 262144 for row in rec["verification"]["timed_region"]["checked"])
-    for leg in ("kitti_like", "sharded_replay", "fullhd_2M", "streamed_input", "single_sequence"):
+    for leg in ("kitti_like", "tum_like", "sharded_replay", "fullhd_2M", "streamed_input", "single_sequence", "dropin_pcie_inclusive", "multi_gpu"):
         assert leg in rec, leg
+    assert rec["multi_gpu"]["backend"] == "nccl" and rec["multi_gpu"]["final_cloud_all_gather_ms"] > 0  # (RCCL ran: a group of one)
+    assert 0.9 <= rec["tum_like"]["ratio_to_ideal_sensor"] <= 1.1 and rec["roofline"]["own_bytes"]["frac"] > 0
 
 
 def test_settled_mean_depth_shortcut(hostemu_lib):
