@@ -361,6 +361,10 @@ class stdout_to_stderr:
 
     def __exit__(self, *a):
         sys.stdout.flush()
+        # (C stdio is fully buffered when stdout is a file or a pipe: without this the banner would sit in libc's buffer
+        # and come out on fd 1 at exit, after the JSON line)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         os.dup2(self.saved, 1)
         os.close(self.saved)
 

@@ -1015,7 +1015,11 @@ def test_message_log_replay_driver(mods, tmp_path):
 
 def _bench_line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    # the contract is ONE line on stdout, and stdout is a pipe here: what a native library left in libc's buffer (RCCL's
+    # banner) would come out after the JSON at exit
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    return json.loads(lines[0])
 
 
 def _kitti_layout(tmp_path, cam, scene, n, synth):
