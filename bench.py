@@ -415,8 +415,8 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
     uploaded on the stream that runs its superpixel stages, right in front of them: dsm_replay_enqueue_host), keyframe indices
     restarting at its first frame, the map resident; the final clouds are merged by one all-gather of the counts and one of the
     padded clouds (RCCL).  A step = F frames of every rank's subsequence; the warm-up steps are replayed first (same engine,
-    same map), the K timed steps between two barriers as ONE streamed replay.  Rank 0's final map is checked against the CPU
-    oracle's replay of the same subsequence, started beside the GPU work."""
+    same map), the K timed steps between two barriers as ONE streamed replay.  Every rank's final map is checked against the CPU
+    oracle's replay of its own subsequence, started beside the GPU work."""
     import hashlib
     import torch
     from densesurfelmapping_amd import api, synth, replay as rp
@@ -425,8 +425,9 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
     shards = rp.shard_subsequences(world * per_rank, world)
     a, b = shards[rank]
     oracle_job, spec = None, None
-    if rank == 0 and not args.no_verify and per_rank <= 1600:
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    if not args.no_verify and per_rank <= 1600:  # every rank checks its own shard (the others start behind rank 0's build: the barrier below)
+        if rank == 0:
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
         spec = {"subsequence": 0, "camera": "KITTI_1226", "seed": 12345, "period": 50, "phase": a, "frames": per_rank}
     if world > 1 and rank != 0:
         dist.barrier()  # rank 0 renders the scene's period (cached in /tmp), the others read it
@@ -535,10 +536,18 @@ def sharded_workload(args, world, rank, device, dist, coll_dev, group_error):
             oracle_job.kill()
             rec = None
         same = bool(rec) and rec["surfels"] == len(got) and rec["sha256"] == hashlib.sha256(canon_bytes(got)).hexdigest()
-        out["verified"] = out["verified_timed_region"] = bool(same) if rec else None
-        out["verification"] = {"what": f"rank 0's final map (frames {a}..{b - 1} of the sequence from an empty map, warm-up and timed steps) against the "
+        rows = [[int(same) if rec else -1, int(len(got)), rec["surfels"] if rec else 0]]
+        if world > 1:
+            mine = torch.tensor(rows[0], dtype=torch.int64, device=coll_dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rows = [[int(v) for v in t_.tolist()] for t_ in every]
+        out["verified"] = out["verified_timed_region"] = all(v[0] == 1 for v in rows) if all(v[0] >= 0 for v in rows) else None
+        out["verification"] = {"what": "every rank's final map (its shard of the sequence from an empty map, warm-up and timed steps) against the "
                                        "CPU oracle's replay of the same subsequence, NaN-canonical SHA-256 of the whole map",
-                               "surfels": int(len(got)), "oracle_surfels": rec["surfels"] if rec else None, "equal": same if rec else None}
+                               "surfels": rows[0][1], "oracle_surfels": rows[0][2] if rows[0][0] >= 0 else None, "equal": bool(rows[0][0]) if rows[0][0] >= 0 else None,
+                               "ranks": [{"rank": r_, "frames": [shards[r_][0], shards[r_][1] - 1], "surfels": v[1], "oracle_surfels": v[2],
+                                          "equal": None if v[0] < 0 else bool(v[0])} for r_, v in enumerate(rows)]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cam, src.scene, src._period, 50, W * F, per_rank)
     m_mean = n_final / 2.0
@@ -669,6 +678,13 @@ def main():
     from densesurfelmapping_amd import api
 
     torch, device, dist, coll_dev, group_error = open_group(args, world, rank, local_rank)
+    # Every OTHER rank checks a subsequence of its own too (the first of its first batch): started behind the rendezvous, by
+    # which time rank 0 has built the oracle; the verdicts are gathered at the end (`verification.ranks`).
+    verify_ranks = world > 1 and n_bat_plan and not args.no_verify and total_frames <= 1600 and args.workload == "headline"
+    if verify_ranks and rank > 0:
+        oracle_specs = [{"subsequence": 0, "camera": "KITTI_1226", "seed": 12345 + 1000 * rank + 17 * scene_of[0], "period": period,
+                         "phase": phase_of[0], "frames": total_frames}]
+        oracle_jobs = start_oracle_replays(oracle_specs)
 
     total = (W + K) * F
     lo_t, hi_t = W * F, total  # frame indices of the timed region, per subsequence
@@ -1551,6 +1567,31 @@ def main():
         out["valu_issue"] = valu_issue(fps / world, clock.ghz())
         out["clocks"] = clock.other()
 
+    if verify_ranks:
+        # one row per rank: [verdict (1 equal, 0 different, -1 no verdict), surfels of the GPU's map, surfels of the oracle's]
+        row = [-1, 0, 0]
+        if rank == 0:
+            mine_rows = (out.get("verification") or {}).get("timed_region", {}).get("checked") or []
+            if mine_rows:
+                row = [int(all(r["equal"] for r in mine_rows)), mine_rows[0]["surfels"], mine_rows[0]["oracle_surfels"] or 0]
+        elif oracle_jobs:
+            try:
+                so, _ = oracle_jobs[0].communicate(timeout=300.0)
+                rec = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+                n_gpu, sha_gpu = end_maps[0]
+                row = [int(rec["surfels"] == n_gpu and rec["sha256"] == sha_gpu), n_gpu, rec["surfels"]]
+            except (subprocess.TimeoutExpired, IndexError, ValueError):
+                oracle_jobs[0].kill()
+            oracle_jobs = []
+        mine = torch.tensor(row, dtype=torch.int64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if rank == 0:
+            rows = [[int(v) for v in t.tolist()] for t in every]
+            out["verification"]["ranks"] = [{"rank": r, "subsequence": 0, "frames": total_frames, "surfels": v[1], "oracle_surfels": v[2],
+                                             "equal": None if v[0] < 0 else bool(v[0])} for r, v in enumerate(rows)]
+            out["verified"] = bool(out.get("verified")) and all(v[0] == 1 for v in rows)
+            out["verified_timed_region"] = bool(out.get("verified_timed_region")) and all(v[0] == 1 for v in rows)
     for job in oracle_jobs:  # (the verification block did not run: e.g. --mode streams)
         job.kill()
     for ff in handles:

@@ -1168,7 +1168,8 @@ def test_bench_ranks_on_one_gpu(world, workload):
     node's eight, sharing the one GPU of the test box; collectives on gloo (the driver runs the real thing on RCCL).  Launched
     the way a user would: `python bench.py --gpus N` starts its own ranks.  `headline`: the weak-scaled batched replay;
     `sharded`: BASELINE configs[2] itself -- one sequence cut into one streamed subsequence per rank.  A multi-rank line is
-    checked like a one-rank line: rank 0's maps of the TIMED run against the CPU oracle's replay of the same frames."""
+    checked like a one-rank line, on EVERY rank: maps the TIMED run left behind against the CPU oracle's replay of the same frames
+    (rank 0 one subsequence per batch, the other ranks one each; sharded: every rank its shard), the verdicts gathered."""
     import subprocess
     import sys
     env = dict(os.environ, DSM_BENCH_BACKEND="gloo", DSM_BENCH_ONE_DEVICE="1")
@@ -1191,6 +1192,8 @@ def test_bench_ranks_on_one_gpu(world, workload):
     # value is the whole job over the slowest rank's time: never more than the sum of the ranks' own rates
     assert out["value"] <= sum(mg["per_rank_frames_per_s"]) * 1.001
     assert out["verified"] is True and out["verified_timed_region"] is True, out.get("verification")
+    ranks = out["verification"]["ranks"]  # every rank checked a map of its own against the oracle, not only rank 0
+    assert [r_["rank"] for r_ in ranks] == list(range(world)) and all(r_["equal"] is True and r_["surfels"] == r_["oracle_surfels"] > 0 for r_ in ranks), ranks
     if workload == "sharded":
         assert len(mg["per_rank_surfels"]) == world and min(mg["per_rank_surfels"]) > 0 and len(out["config"]["shards"]) == world
 
