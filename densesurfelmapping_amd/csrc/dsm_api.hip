@@ -2091,6 +2091,22 @@ hipError_t batch_streams_reserve(int device) {
     if (device < 0 || device >= 64) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lk(g_batch_streams.mu);
     if (g_batch_streams.made[device]) return hipSuccess;
+    // "A queue each" holds only while the queues carry equally many streams when the four are created.  A host that has used
+    // the device before the first dsm_create -- torch.cuda.set_device, torch.distributed's eager RCCL communicator, any stream
+    // made and destroyed -- leaves them uneven, and the fewest-streams rule then puts two of the four on one queue (rocprofv3
+    // queue ids of bench.py's four batches: queues 2, 3, 4, 4, queue 1 left to the host's own stream).  Measured on one box,
+    // alternating: the headline 41.2 k frames/s like that against 45.9 k with a queue each; one streamed sequence with an RCCL
+    // group open 12.7-13.5 k against 15.3-17.9 k (round 6, profiles/r06_queue_levelling.md).  So the pool is levelled first:
+    // ballast streams fill the emptier queues up (the same rule, working for us), the four are created on the level pool, the
+    // ballast goes again -- the four stay where they are.
+    constexpr int kBallast = 24;
+    hipStream_t ballast[kBallast] = {};
+    for (int i = 0; i < kBallast; i++)
+        if (hipStreamCreateWithFlags(&ballast[i], hipStreamNonBlocking) != hipSuccess) { ballast[i] = nullptr; break; }
+    struct Drop {
+        hipStream_t *b;
+        ~Drop() { for (int i = 0; i < kBallast; i++) if (b[i]) (void)hipStreamDestroy(b[i]); }
+    } drop{ballast};
     for (int i = 0; i < kBatchStreams; i++) {
         const hipError_t e = hipStreamCreateWithFlags(&g_batch_streams.st[device][i], hipStreamNonBlocking);
         if (e != hipSuccess) { // all or nothing: the next dsm_create tries again

@@ -234,6 +234,43 @@ def test_other_baseline_sizes(mods, camera, frames):
         assert border.any() and (lab[border] == -1).all() and (lab[~border] >= 0).all()
 
 
+@pytest.mark.parametrize("camera", ["KITTI_1241", "KITTI_1242"])
+def test_launch_default_sizes_through_pruning(mods, camera):
+    """The launch files' own image sizes (kitti_orb.launch: 1241x376; KITTI raw 1242x375, whose last columns have no candidate
+    superpixel) for longer than the four frames of test_other_baseline_sizes: 60 frames over a 15-frame loop, so that surfels
+    are revisited, pruned (FF.cpp:207-211) and refilled / compacted (SM.cpp:1087-1109) at these ragged sizes too -- frame by
+    frame (one graph replay each) and again as one pipelined replay with eight frames per batched launch, against the oracle."""
+    api, synth, ob = mods
+    cam, scene = getattr(synth, camera), synth.Scene(seed=78, frames_per_period=15)
+    period, n = scene.frames_per_period, 60
+    frames = list(synth.sequence(cam, scene, n))
+    orc = ob.PortOracle(cam)
+    lo, want, holes = np.zeros(0, ob.SURFEL_DTYPE), [], 0
+    for t, img, dep, pose, ref in frames:
+        before = len(lo)
+        lo, ko = orc.fuse_map(ref, img, dep, pose, lo)
+        holes += before + ko - len(lo)
+        want.append((ko, len(lo), lo.copy() if (t + 1) % 20 == 0 else None))
+    assert holes > 500, "nothing was pruned: the case lost its point"
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20)
+    for t in range(period):
+        ff.frame_upload(t, frames[t][1], frames[t][2])
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    for (t, img, dep, pose, ref), (ko, n_lo, snap) in zip(frames, want):
+        ff.fuse_frame_resident(t % period, ref, pose)
+        assert (ff.last_new_count(), ff.map_size()) == (ko, n_lo), f"{camera} frame {t}"
+        if snap is not None:
+            assert fields_equal(ff.map_download(), snap.astype(api.SURFEL_DTYPE)) == [], f"{camera}: map after frame {t}"
+    ff.close()
+    ff = api.FusionFunctions.from_camera(cam, frame_slots=period, surfel_capacity=1 << 20, pipeline_depth=24)
+    for t in range(period):
+        ff.frame_upload(t, frames[t][1], frames[t][2])
+    ff.map_upload(np.zeros(0, api.SURFEL_DTYPE))
+    ff.replay_enqueue(*ff.pack_replay([f[0] % period for f in frames], [f[4] for f in frames], [f[3] for f in frames]))
+    assert fields_equal(ff.map_download(), lo.astype(api.SURFEL_DTYPE)) == [], f"{camera}: pipelined replay"
+    ff.close()
+
+
 def test_api_errors_are_reported(mods):
     """The reference returns void and prints; the ABI returns a status and a message, and never computes on bad input."""
     api, synth, ob = mods
