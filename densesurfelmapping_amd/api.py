@@ -43,7 +43,7 @@ DSM_MAX_STAGES = 32
 # every symbol include/dsm.h declares
 ABI_SYMBOLS = (
     "dsm_abi_version", "dsm_config_init", "dsm_create", "dsm_destroy", "dsm_last_error",
-    "dsm_host_alloc", "dsm_host_free",
+    "dsm_host_alloc", "dsm_host_free", "dsm_host_pack_frames",
     "dsm_fuse_initialize_map", "dsm_fuse_map", "dsm_fuse_initialize_map_inv", "dsm_fuse_map_inv",
     "dsm_fuse_frame_resident_inv", "dsm_replay_enqueue_inv", "dsm_batch_replay_enqueue_inv",
     "dsm_map_upload", "dsm_map_size", "dsm_map_capacity", "dsm_map_download", "dsm_map_copy_to_device",
@@ -105,6 +105,7 @@ def load_library():
     lib.dsm_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
     lib.dsm_host_free.argtypes = [_vp]
     lib.dsm_host_free.restype = None
+    lib.dsm_host_pack_frames.argtypes = [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t]
     lib.dsm_fuse_initialize_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int32,
                                             _vp, C.c_int32, _vp]
     lib.dsm_fuse_map.argtypes = [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_int32, _vp]
@@ -573,6 +574,31 @@ class PinnedFrames:
     def set(self, i, image, depth):
         self.image(i)[...] = image
         self.depth(i)[...] = depth
+
+    def set_many(self, first, images, depths):
+        """frames first .. first+n-1 from n (image uint8 [H,W], depth float32 [H,W]) pairs, copied by the library's host
+        threads (dsm_host_pack_frames; the GIL is released for the call)"""
+        n = len(images)
+        if n == 0:
+            return
+        if first < 0 or first + n > self.n or len(depths) != n:
+            raise ValueError("frames out of range")
+        keep = []
+        for im, dp in zip(images, depths):
+            im = im if (im.dtype == np.uint8 and im.strides[1] == 1) else np.ascontiguousarray(im, np.uint8)
+            dp = dp if (dp.dtype == np.float32 and dp.strides[1] == 4) else np.ascontiguousarray(dp, np.float32)
+            if im.shape != (self.h, self.w) or dp.shape != (self.h, self.w):
+                raise ValueError("frame size")
+            keep.append((im, dp))
+        ip = (C.c_void_p * n)(*[k[0].ctypes.data for k in keep])
+        dp_ = (C.c_void_p * n)(*[k[1].ctypes.data for k in keep])
+        ist = (C.c_size_t * n)(*[k[0].strides[0] for k in keep])
+        dst = (C.c_size_t * n)(*[k[1].strides[0] for k in keep])
+        rc = self._lib.dsm_host_pack_frames(n, self.w, self.h, ip, ist, dp_, dst,
+                                            C.c_void_p(self._img[first].ctypes.data), C.c_size_t(self.pitch), C.c_size_t(self._bytes_img),
+                                            C.c_void_p(self._dep[first].ctypes.data), C.c_size_t(self.pitch * 4), C.c_size_t(self._bytes_dep))
+        if rc:
+            raise DsmError(rc, self._lib.dsm_last_error(None).decode())
 
     def close(self):
         if getattr(self, "_p", None):

@@ -1288,6 +1288,47 @@ void dsm_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+// The caller's frames (one pointer + row step each: n cv::Mat pairs) into page-locked memory laid out like frame slots, by a
+// few host threads of the library (process-wide, made at the first call; the caller's thread takes part): one core copies
+// ~10 GB/s of 1226-pixel rows, a replay at fifteen thousand frames a second needs 35.
+int dsm_host_pack_frames(int32_t n, int32_t width, int32_t height, const uint8_t *const *images, const size_t *image_steps,
+                         const float *const *depths, const size_t *depth_steps, uint8_t *dst_image, size_t dst_img_step,
+                         size_t dst_img_frame_step, float *dst_depth, size_t dst_depth_step, size_t dst_depth_frame_step) {
+    if (n < 0 || width <= 0 || height <= 0) return fail(nullptr, DSM_E_INVALID, "dsm_host_pack_frames: negative count or empty image");
+    if (n == 0) return DSM_OK;
+    if (!images || !image_steps || !depths || !depth_steps || !dst_image || !dst_depth) return fail(nullptr, DSM_E_INVALID, "dsm_host_pack_frames: null argument");
+    const size_t row_i = (size_t)width, row_d = (size_t)width * 4;
+    if (dst_img_step < row_i || dst_depth_step < row_d) return fail(nullptr, DSM_E_INVALID, "dsm_host_pack_frames: destination row step smaller than a row");
+    if (n > 1 && (dst_img_frame_step < dst_img_step * (size_t)height || dst_depth_frame_step < dst_depth_step * (size_t)height))
+        return fail(nullptr, DSM_E_INVALID, "dsm_host_pack_frames: destination frame step smaller than a frame");
+    for (int i = 0; i < n; i++)
+        if (!images[i] || !depths[i] || image_steps[i] < row_i || depth_steps[i] < row_d)
+            return fail(nullptr, DSM_E_INVALID, "dsm_host_pack_frames: frame %d: null plane or row step smaller than a row", i);
+    static std::mutex mu; // one packing call at a time: the pool runs one job
+    static HostPool *pool = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        pool = new HostPool(hw >= 32 ? 7 : hw >= 8 ? 3 : 1);
+    }
+    // a task = the image plane of a frame, or a quarter of its depth plane's rows (equal bytes)
+    constexpr int kParts = 5;
+    pool->run(n * kParts, [&](int t) {
+        const int i = t / kParts, part = t % kParts;
+        if (part == 0) {
+            const uint8_t *src = images[i];
+            uint8_t *dst = dst_image + (size_t)i * dst_img_frame_step;
+            for (int y = 0; y < height; y++) memcpy(dst + (size_t)y * dst_img_step, src + (size_t)y * image_steps[i], row_i);
+        } else {
+            const int y0 = (int)((int64_t)height * (part - 1) / 4), y1 = (int)((int64_t)height * part / 4);
+            const char *src = (const char *)depths[i];
+            char *dst = (char *)dst_depth + (size_t)i * dst_depth_frame_step;
+            for (int y = y0; y < y1; y++) memcpy(dst + (size_t)y * dst_depth_step, src + (size_t)y * depth_steps[i], row_d);
+        }
+    });
+    return DSM_OK;
+}
+
 int dsm_seed_count(const dsm_handle *h) { return h ? h->hc.n_seed : DSM_E_INVALID; }
 
 int dsm_stream(dsm_handle *h, void **hip_stream) {

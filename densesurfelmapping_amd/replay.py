@@ -243,21 +243,19 @@ class HipEngine:
             self._pins = [api.PinnedFrames(ff, C) for _ in range(self.BLOCKS)]
 
         def produce():  # decode / render / copy chunk k into page-locked block k mod BLOCKS, as soon as that block is free
-            from concurrent.futures import ThreadPoolExecutor
             try:
-                with ThreadPoolExecutor(2) as copiers:  # (numpy's copies drop the GIL: two of them move twice the bytes)
-                    for k, (t0, n) in enumerate(chunks):
-                        free.acquire()
-                        if stop.is_set():
-                            return
-                        pf = self._pins[k % self.BLOCKS]
-                        poses, jobs = [], []
-                        for i, (image, depth, pose) in enumerate(source.frames(t0, t0 + n)):
-                            jobs.append(copiers.submit(pf.set, i, image, depth))
-                            poses.append(pose)
-                        for j in jobs:
-                            j.result()
-                        ready.put((k, poses, None))
+                for k, (t0, n) in enumerate(chunks):
+                    free.acquire()
+                    if stop.is_set():
+                        return
+                    images, depths, poses = [], [], []
+                    for image, depth, pose in source.frames(t0, t0 + n):
+                        images.append(image)
+                        depths.append(depth)
+                        poses.append(pose)
+                    # one call for the chunk: the library's host threads copy it (dsm_host_pack_frames), no GIL held
+                    self._pins[k % self.BLOCKS].set_many(0, images, depths)
+                    ready.put((k, poses, None))
                 ready.put(None)
             except BaseException as e:  # noqa: BLE001 -- handed to the consumer
                 ready.put((None, None, e))

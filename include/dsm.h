@@ -161,6 +161,14 @@ int dsm_fuse_map_inv(dsm_handle *h, int reference_frame_index, const uint8_t *im
  * rate without a staging copy.  Plain malloc'ed buffers work too, slower. */
 int dsm_host_alloc(void **out, size_t bytes);
 void dsm_host_free(void *p);
+/* n of the caller's frames (frame i: images[i] / depths[i] with their row steps in bytes -- n cv::Mat pairs as
+ * SurfelMap::image_input / depth_input receive them, surfel_map.cpp:83-101) copied into page-locked memory in the layout the
+ * asynchronous uploads read (dsm_frames_upload_async, dsm_replay_enqueue_host: rows dst_*_step bytes apart, frames
+ * dst_*_frame_step apart) by the library's host threads, the caller's among them; pad bytes are left as they are.  Synchronous;
+ * calls from several threads take turns. */
+int dsm_host_pack_frames(int32_t n, int32_t width, int32_t height, const uint8_t *const *images, const size_t *image_steps,
+                         const float *const *depths, const size_t *depth_steps, uint8_t *dst_image, size_t dst_img_step,
+                         size_t dst_img_frame_step, float *dst_depth, size_t dst_depth_step, size_t dst_depth_frame_step);
 
 /* ---- resident path: map and frames stay in HBM, calls are asynchronous on the handle's stream */
 

@@ -355,6 +355,36 @@ def test_c_abi_exports_every_declared_symbol():
     assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
 
 
+def test_host_pack_frames():
+    """dsm_host_pack_frames (host code only: no GPU needed): the caller's frames -- contiguous and strided rows -- land in the
+    slot layout row for row, pad bytes untouched; bad steps and null planes are refused before anything is copied."""
+    from densesurfelmapping_amd import api, build
+    build.build_library()
+    lib = api.load_library()
+    rng = np.random.default_rng(1)
+    n, w, h = 9, 166, 103
+    pitch = (w + 63) // 64 * 64
+    wide_i, wide_d = rng.integers(0, 256, (h, w + 9), dtype=np.uint8), rng.random((h, w + 5), dtype=np.float32)
+    ims = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(n - 1)] + [wide_i[:, 3:3 + w]]
+    dps = [rng.random((h, w), dtype=np.float32) for _ in range(n - 1)] + [wide_d[:, 2:2 + w]]
+    dst_i, dst_d = np.full((n, h, pitch), 7, np.uint8), np.full((n, h, pitch), -1, np.float32)
+
+    def call(n_, ims_, dps_, img_step=pitch):
+        ip, dp = (C.c_void_p * len(ims_))(*[a.ctypes.data if a is not None else None for a in ims_]), (C.c_void_p * len(dps_))(*[a.ctypes.data for a in dps_])
+        ist = (C.c_size_t * len(ims_))(*[a.strides[0] if a is not None else 0 for a in ims_])
+        dst = (C.c_size_t * len(dps_))(*[a.strides[0] for a in dps_])
+        return lib.dsm_host_pack_frames(n_, w, h, ip, ist, dp, dst, C.c_void_p(dst_i.ctypes.data), img_step, pitch * h,
+                                        C.c_void_p(dst_d.ctypes.data), pitch * 4, pitch * h * 4)
+    assert call(n, ims, dps) == 0
+    for i in range(n):
+        assert np.array_equal(dst_i[i, :, :w], ims[i]) and np.array_equal(dst_d[i, :, :w], dps[i]), i
+    assert (dst_i[:, :, w:] == 7).all() and (dst_d[:, :, w:] == -1).all(), "pad bytes were written"
+    assert call(0, ims, dps) == 0
+    assert call(n, ims, dps, img_step=w - 1) == -1 and "row step" in lib.dsm_last_error(None).decode()
+    assert call(n, ims[:-1] + [None], dps) == -1 and "frame 8" in lib.dsm_last_error(None).decode()
+    # the Python mirror: PinnedFrames.set_many needs page-locked memory (a GPU runtime); its argument marshalling is the call above
+
+
 def test_no_cpu_fallback_without_gpu():
     """On a box without a GPU the product path must fail loudly, not compute on the CPU."""
     import torch
