@@ -52,5 +52,34 @@ def build_library(force: bool = False, verbose: bool = False, defines=(), out: s
     return out
 
 
+MERGE_LIB_PATH = os.path.join(HERE, "libdsm_merge_rccl.so")
+
+
+def build_merge_library(force: bool = False, verbose: bool = False) -> str:
+    """include/dsm_merge.h: the RCCL merge of the final clouds for C++ hosts -- a library of its own (links librccl), so that
+    libdsm_hip.so carries no RCCL dependency."""
+    src = os.path.join(CSRC, "dsm_merge_rccl.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "dsm_merge.h"), os.path.join(HERE, "..", "include", "dsm.h")]
+    if not force and os.path.exists(MERGE_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(MERGE_LIB_PATH) for d in deps):
+        return MERGE_LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "hip", src, "-lrccl", "-o", MERGE_LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(MERGE_LIB_PATH + ".tmp", MERGE_LIB_PATH)
+    return MERGE_LIB_PATH
+
+
+def build_merge_test(out: str) -> str:
+    """tests/cpp/merge_rccl_test.cpp against the merge library (run by the -m gpu suite)"""
+    root = os.path.dirname(HERE)
+    build_merge_library()
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", os.path.join(root, "tests", "cpp", "merge_rccl_test.cpp"),
+                    "-L" + HERE, "-ldsm_merge_rccl", "-lrccl", "-Wl,-rpath," + HERE, "-o", out], check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_merge_library(force="--force" in sys.argv, verbose=True))

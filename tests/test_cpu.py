@@ -352,6 +352,13 @@ def test_c_abi_exports_every_declared_symbol():
             assert hasattr(lib, name), name
     lib.dsm_abi_version.restype = C.c_int
     assert lib.dsm_abi_version() == 4
+    # include/dsm_merge.h: the RCCL merge for C++ hosts, a library of its own
+    mlib = C.CDLL(build.build_merge_library())
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dsm_merge.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(dsm_[a-z_0-9]+)\s*\(", header))
+    assert declared == {"dsm_merge_clouds_rccl", "dsm_merge_last_error"} and all(hasattr(mlib, n) for n in declared)
+    mlib.dsm_merge_clouds_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    assert mlib.dsm_merge_clouds_rccl(None, 1, 0, None, 0, None, 0, None, None) == -1  # (argument checks come before any device call)
     assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
 
 

@@ -1309,6 +1309,25 @@ def test_merge_clouds_through_rccl_on_one_gpu(tmp_path):
     assert out["verified"] is True and out["verified_timed_region"] is True
 
 
+def test_cpp_merge_clouds_through_rccl(tmp_path):
+    """include/dsm_merge.h, the merge of BASELINE configs[2] for a C++ host: tests/cpp/merge_rccl_test.cpp creates an RCCL
+    communicator of one (ncclCommInitRank) on the test box's GPU and merges a small cloud, an empty one and a 2 GB one through
+    dsm_merge_clouds_rccl -- all-gather of the counts, all-gather of the padded cloud -- and checks capacity and argument errors."""
+    import shutil
+    import subprocess
+    from densesurfelmapping_amd import build
+    exe = os.path.join(ROOT, "tests", "_build", "merge_rccl_test")
+    if os.path.exists(shutil.which("hipcc") or "/opt/rocm/bin/hipcc"):
+        exe = build.build_merge_test(str(tmp_path / "merge_rccl_test"))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("dsm_merge_clouds_rccl, world 1:", rec)
+    assert rec["surfels_2GB"] * 44 > 2_000_000_000 and 0 < rec["ms_2GB"] < 1000
+
+
 def test_bench_sharded_workload_one_gpu():
     """`bench.py --workload sharded` at --gpus 1: BASELINE configs[2]'s own path on one rank -- one subsequence streamed from
     page-locked host memory through one handle -- with its final map checked against the CPU oracle's replay of the same 192
