@@ -179,6 +179,11 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_seed_points(const
 // inlier of its own superpixel (FF.cpp:846-850: member, depth > 0.05, |mean depth - depth| < HUBER_RANGE), written into
 // a 12 B/pixel plane; the other pixels' entries are stale and never read.  (calculate_pixels_norms computes all of them;
 // only these are ever read, FF.cpp:852-857.)
+// A thread takes a COLUMN of four pixels (a workgroup 64 x 16): a quarter of the waves -- a launch over 32 frames was 238 000 waves of
+// ~150 instructions each, a third of them address arithmetic and context loads, and beside three other batches' kernels it took
+// four times as long as alone (wave dispatch) -- the depth below a pixel is the next pixel's own, and everything a pixel may need
+// is requested before the first result is looked at.
+constexpr int kNormalRows = 4;
 template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
@@ -187,28 +192,47 @@ template <bool BATCH> __global__ __launch_bounds__(256) void k_pixel_normals(con
     const FrameParams &fp = frame_params(c);
     const float *dep = frame_depth(c, fp);
     const int w = c->w, h = c->h, pitch = c->pitch;
-    const int x = blk.x * 64 + (threadIdx.x & 63), y = blk.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const unsigned p = (unsigned)(__mul24(y, pitch) + x), p4 = p << 2;
-    const float d = ld_off(dep, p4);
-    const int l = label_at(c->label, p);
-    // only the depth inliers of their own superpixel are ever read (k_seed_stats asks for exactly those): nothing is
-    // stored for any other pixel; an inlier on the image border has no normal (FF.cpp:670-677) and stores zeros
-    if (!(l >= 0 && d > flt_below(0.05))) return;                      // (double)d > 0.05
-    const float md = ld_off(reinterpret_cast<const float *>(c->core), ((unsigned)l << 4) + 12u);
-    const bool interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2;
-    float d_right = 0.0f, d_down = 0.0f;
-    if (interior) { // (neighbours fetched before the inlier test is known: one round trip)
-        d_right = ld_off(dep, p4 + 4u);
-        d_down = ld_off(dep, p4 + ((unsigned)pitch << 2));
+    const int x = blk.x * 64 + (threadIdx.x & 63);
+    const int y0 = blk.y * (4 * kNormalRows) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kNormalRows; // (wave-uniform)
+    if (x >= w || y0 >= h) return;
+    const unsigned p0 = (unsigned)(__mul24(y0, pitch) + x), row = (unsigned)pitch;
+    // labels and depths of the column (and the row below it), the right-hand neighbours: all in flight at once.  Rows past the
+    // image read the last row again (never used: a pixel there is skipped below)
+    int l[kNormalRows];
+    float d[kNormalRows + 1], dr[kNormalRows];
+    const bool has_right = x <= w - 2;
+#pragma unroll
+    for (int r = 0; r <= kNormalRows; r++) {
+        const unsigned p = p0 + row * (unsigned)min(r, h - 1 - y0);
+        d[r] = ld_off(dep, p << 2);
+        if (r < kNormalRows) {
+            l[r] = label_at(c->label, p);
+            dr[r] = has_right ? ld_off(dep, (p << 2) + 4u) : 0.0f;
+        }
     }
     const float rx0 = ld_off(c->ray_x, (unsigned)x << 2), rx1 = ld_off(c->ray_x, ((unsigned)x << 2) + 4u);
-    const float ry0 = ld_off(c->ray_y, (unsigned)y << 2), ry1 = ld_off(c->ray_y, ((unsigned)y << 2) + 4u);
-    if (!(fabsf(md - d) < flt_above(c->huber))) return;
-    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-    if (interior) pixel_normal_rays(rx0, rx1, ry0, ry1, d, d_right, d_down, nx, ny, nz);
-    float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(c->normals) + p * 12u);
-    o[0] = nx; o[1] = ny; o[2] = nz;
+    float ry[kNormalRows + 1];
+#pragma unroll
+    for (int r = 0; r <= kNormalRows; r++) ry[r] = ld_off(c->ray_y, (unsigned)min(y0 + r, h) << 2); // (ray_y has h + 1 entries)
+    // only the depth inliers of their own superpixel are ever read (k_seed_stats asks for exactly those): nothing is
+    // stored for any other pixel; an inlier on the image border has no normal (FF.cpp:670-677) and stores zeros
+    float md[kNormalRows];
+    bool member[kNormalRows];
+#pragma unroll
+    for (int r = 0; r < kNormalRows; r++) {
+        member[r] = y0 + r < h && l[r] >= 0 && d[r] > flt_below(0.05); // (double)d > 0.05
+        md[r] = member[r] ? ld_off(reinterpret_cast<const float *>(c->core), ((unsigned)l[r] << 4) + 12u) : 0.0f;
+    }
+    const float hub = flt_above(c->huber);
+#pragma unroll
+    for (int r = 0; r < kNormalRows; r++) {
+        if (!(member[r] && fabsf(md[r] - d[r]) < hub)) continue;
+        const int y = y0 + r;
+        float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+        if (x >= 1 && has_right && y >= 1 && y <= h - 2) pixel_normal_rays(rx0, rx1, ry[r], ry[r + 1], d[r], dr[r], d[r + 1], nx, ny, nz);
+        float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(c->normals) + (p0 + row * (unsigned)r) * 12u);
+        o[0] = nx; o[1] = ny; o[2] = nz;
+    }
 }
 
 // k_seed_stats, ONE LANE PER SEED (64 consecutive seeds per wave): calculate_sp_depth_norms up to the plane fit's

@@ -80,7 +80,6 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
     const bool lanes = batched && n_batch >= (lanes_from > 0 ? lanes_from : kLaneBatch);
     const dim3 g_tile1((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<1>::kH - 1) / AssignTile<1>::kH);
     const dim3 g_tile4((hc.w + kTileW - 1) / kTileW, (hc.h + AssignTile<4>::kH - 1) / AssignTile<4>::kH);
-    const dim3 g_pix4((hc.w + 63) / 64, (hc.h + 3) / 4); // thread per pixel, 64 x 4 per block
     const dim3 g_row8((hc.pitch / 8 + 63) / 64, (hc.h + 3) / 4); // thread per eight pixels of a row, 512 x 4 per block
     if (ev) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 40000LL); // 400 us
     DSM_MARK();
@@ -111,7 +110,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
         DSM_MARK();
     }
     if (lanes) {
-        hipLaunchStage(k_pixel_normals<true>, k_pixel_normals<true>, g_pix4, dim3(256));
+        hipLaunchStage(k_pixel_normals<true>, k_pixel_normals<true>, dim3((hc.w + 63) / 64, (hc.h + 4 * kNormalRows - 1) / (4 * kNormalRows)), dim3(256));
         hipLaunchStage(k_seed_stats<true>, k_seed_stats<true>, g_seed_lane, dim3(64));
     } else {
         hipLaunchStage(k_seed_points<false>, k_seed_points<true>, g_seed_wave, dim3(256));
