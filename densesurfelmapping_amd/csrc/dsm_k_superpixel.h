@@ -544,34 +544,47 @@ __device__ __forceinline__ void update_seed_wave(const DeviceCtx *__restrict__ c
 // gathered tmin) held the lane-per-seed kernel to one wave per SIMD.  Here a pixel is resolved once, and neighbouring
 // pixels mostly share their old label: a wave's gather touches a handful of lines.  Pixels beyond every cell's reach keep
 // their -1 (no seed, no tmin).
+// A thread takes the eight pixels of kApplyRows consecutive rows; tmin is fetched only for a pixel whose pick differs from its
+// label (the others keep theirs whatever tmin says: from the second sweep on that is nearly all of them).
+constexpr int kApplyRows = 2;
 template <bool BATCH> __global__ __launch_bounds__(256) void k_apply_labels(const DeviceCtx ctx, const DeviceCtx *__restrict__ batch, int sweep) {
     const BlockOf blk = block_of<BATCH>();
     DeviceCtx batch_ctx;
     if (BATCH) batch_ctx = load_ctx(batch + blk.z);
     const DeviceCtx *__restrict__ c = BATCH ? &batch_ctx : &ctx;
     const int pitch = c->pitch;
-    const int xq = blk.x * 64 + (threadIdx.x & 63), y = blk.y * 4 + (threadIdx.x >> 6);
-    if (8 * xq >= pitch || y >= c->h) return;
-    const int key0 = __mul24(y, pitch) + 8 * xq;
-    const uint4 lab = ld_vec<uint4>(c->label, (unsigned)key0 << 1), cd = ld_vec<uint4>(c->cand, (unsigned)key0 << 1);
-    const unsigned lw[4] = {lab.x, lab.y, lab.z, lab.w}, cw[4] = {cd.x, cd.y, cd.z, cd.w};
-    unsigned l[8], o[8];
-    int t[8];
+    const int xq = blk.x * 64 + (threadIdx.x & 63), y0 = (blk.y * 4 + (threadIdx.x >> 6)) * kApplyRows;
+    if (8 * xq >= pitch || y0 >= c->h) return;
+    uint4 lab[kApplyRows], cd[kApplyRows];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        l[j] = (j & 1) ? lw[j >> 1] >> 16 : lw[j >> 1] & 0xffffu;
-        t[j] = l[j] != (unsigned)kNoLabel ? ld_off(c->tmin, l[j] << 2) : kIntMax;
+    for (int r = 0; r < kApplyRows; r++) {
+        const int key0 = __mul24(min(y0 + r, c->h - 1), pitch) + 8 * xq; // (a row past the image: the last row again, not stored)
+        lab[r] = ld_vec<uint4>(c->label, (unsigned)key0 << 1);
+        cd[r] = ld_vec<uint4>(c->cand, (unsigned)key0 << 1);
     }
-    bool changed = false;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const unsigned pk = (j & 1) ? cw[j >> 1] >> 16 : cw[j >> 1] & 0xffffu;
-        o[j] = t[j] < key0 + j ? pk : l[j];
-        changed = changed || o[j] != l[j];
+    for (int r = 0; r < kApplyRows; r++) {
+        if (y0 + r >= c->h) break;
+        const int key0 = __mul24(y0 + r, pitch) + 8 * xq;
+        const unsigned lw[4] = {lab[r].x, lab[r].y, lab[r].z, lab[r].w}, cw[4] = {cd[r].x, cd[r].y, cd[r].z, cd[r].w};
+        unsigned l[8], pk[8], o[8];
+        int t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            l[j] = (j & 1) ? lw[j >> 1] >> 16 : lw[j >> 1] & 0xffffu;
+            pk[j] = (j & 1) ? cw[j >> 1] >> 16 : cw[j >> 1] & 0xffffu;
+            t[j] = (l[j] != (unsigned)kNoLabel && pk[j] != l[j]) ? ld_off(c->tmin, l[j] << 2) : kIntMax;
+        }
+        bool changed = false;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            o[j] = t[j] < key0 + j ? pk[j] : l[j];
+            changed = changed || o[j] != l[j];
+        }
+        if (changed)
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(c->label) + ((unsigned)key0 << 1)) =
+                make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
     }
-    if (changed)
-        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(c->label) + ((unsigned)key0 << 1)) =
-            make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
 }
 
 // One Huber-Newton pass (FF.cpp:536-553) of up to 64 seeds at once, one chain per lane: a = ordered sum of 2*r over the

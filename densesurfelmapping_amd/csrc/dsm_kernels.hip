@@ -96,7 +96,7 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
             else hipLaunchStage((k_assign<false, false, 1>), (k_assign<false, true, 1>), g_tile1, dim3(256), sweep);
             DSM_MARK();
             hipLaunchStage(k_resolve<false>, k_resolve<true>, dim3(1), dim3(256), sweep);
-            hipLaunchStage(k_apply_labels<false>, k_apply_labels<true>, g_row8, dim3(256), sweep); // (part of the resolve stage: the sweep's label image)
+            hipLaunchStage(k_apply_labels<false>, k_apply_labels<true>, dim3(g_row8.x, (hc.h + 4 * kApplyRows - 1) / (4 * kApplyRows)), dim3(256), sweep); // (part of the resolve stage: the sweep's label image)
             DSM_MARK();
         }
         if (lanes) {
@@ -126,6 +126,10 @@ hipError_t launch_frame(const DeviceCtx &hc, int map_upper_bound, int tail_map_b
     if (fuse_blocks < 1) fuse_blocks = 1;
     const int fuse_cap = batched ? resident_blocks(k_fuse_surfels<true>, 256, kFuseBlocksPerCu) : resident_blocks(k_fuse_surfels<false>, 256, kFuseBlocksPerCu);
     if (fuse_blocks > fuse_cap) fuse_blocks = fuse_cap;
+    // ... for the launch as a whole: the handles of a batch share the cap (round 6).  Capped per handle, a launch over 32 handles
+    // was 24 000 workgroups of one or two trips each, every one of them setting up its context, constants and the two
+    // matrices first (80 scalar instructions per wave); +2.6 % on the headline over five alternating runs
+    if (batched && nz > 1 && fuse_blocks > (fuse_cap / nz > 1 ? fuse_cap / nz : 1)) fuse_blocks = fuse_cap / nz > 1 ? fuse_cap / nz : 1;
     hipLaunchStage(k_fuse_surfels<false>, k_fuse_surfels<true>, dim3(fuse_blocks), dim3(256));
     DSM_MARK();
     // (a map that may be beyond the tail's one-workgroup path gets a workgroup per chunk of its hole bitmap on top; they
