@@ -398,8 +398,8 @@ class FusionFunctions:
 
     def frames_upload_async(self, slot0, pinned, first, n):
         """frames first .. first+n-1 of a PinnedFrames block (slot layout, back to back) into slots slot0 .. slot0+n-1:
-        one transfer per plane for all of them"""
-        assert 0 <= first and first + n <= pinned.n and (pinned.h, pinned.w, pinned.pitch) == (self.height, self.width, self.frame_pitch())
+        one transfer per plane for all of them -- of a block with tight rows too (PinnedFrames(..., tight=True))"""
+        assert 0 <= first and first + n <= pinned.n and (pinned.h, pinned.w) == (self.height, self.width) and pinned.pitch in (self.frame_pitch(), self.width)
         img, dep = pinned.image(first), pinned.depth(first)
         self._check(self._lib.dsm_frames_upload_async(self._h, slot0, n, _ptr(img), img.strides[0], pinned.pitch * pinned.h,
                                                       _ptr(dep), dep.strides[0], pinned.pitch * pinned.h * 4))
@@ -545,15 +545,19 @@ class PinnedFrames:
     """n frames in page-locked host memory (dsm_host_alloc), rows laid out with a handle's slot pitch, pad columns zero:
     image(i) / depth(i) are [H,W] views that dsm_frame_upload_async moves in one transfer per plane."""
 
-    def __init__(self, ff, n: int):
+    def __init__(self, ff, n: int, tight: bool = False):
         """ff: a FusionFunctions (its slot layout), or a (height, width) pair -- the pitch is then the library's rule,
-        ceil(width / 64) * 64 elements per row, and frames_upload_async checks it against the handle's."""
+        ceil(width / 64) * 64 elements per row, and frames_upload_async checks it against the handle's.  tight=True: rows
+        `width` elements apart, frames back to back (`pitch` = width) -- the asynchronous uploads then move no pad bytes over
+        the link and set the rows to the slots' pitch on the device."""
         self._lib = load_library()
         if isinstance(ff, tuple):
             self.n, self.h, self.w = n, int(ff[0]), int(ff[1])
             self.pitch = (self.w + 63) // 64 * 64
         else:
             self.n, self.h, self.w, self.pitch = n, ff.height, ff.width, ff.frame_pitch()
+        if tight:
+            self.pitch = self.w
         self._bytes_img, self._bytes_dep = self.pitch * self.h, self.pitch * self.h * 4
         p = _vp()
         rc = self._lib.dsm_host_alloc(C.byref(p), n * (self._bytes_img + self._bytes_dep))

@@ -163,6 +163,8 @@ hipError_t launch_warp(dsm_surfel *surfels, const int32_t *n_ptr, int n_fixed, c
                        const int32_t *d_offsets, int n_groups, int n_upper, hipStream_t st,
                        const uint8_t *d_group_on = nullptr, float4 *d_cloud = nullptr);
 hipError_t launch_mark(const DeviceCtx &ctx, int key, int n_upper, hipStream_t st);
+hipError_t launch_repack_frames(uint8_t *d_img, float *d_depth, int pitch, int64_t slot_elems, const uint8_t *s_img, const float *s_depth, int w, int h,
+                                int frames, hipStream_t st);
 hipError_t launch_repack(uint8_t *d_img, float *d_depth, int pitch, const uint8_t *s_img, const float *s_depth, int w, int h,
                          hipStream_t st);
 hipError_t launch_extract_marked(const DeviceCtx &ctx, dsm_surfel *out, int cap, float4 *cloud_out, hipStream_t st);

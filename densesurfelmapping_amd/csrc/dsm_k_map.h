@@ -804,6 +804,24 @@ template <typename T> __global__ __launch_bounds__(256) void k_repack_rows(T *__
         dst[(int64_t)y * pitch + x] = src[i];
     }
 }
+// ... and n of them at once (the asynchronous uploads: frames back to back, tight on the source side, slot after slot on the other)
+template <typename T> __global__ __launch_bounds__(256) void k_repack_frames(T *__restrict__ dst, int pitch, int64_t dst_frame, const T *__restrict__ src, int w, int n) {
+    const T *s = src + (int64_t)blockIdx.y * n;
+    T *d = dst + (int64_t)blockIdx.y * dst_frame;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int y = i / w, x = i - y * w;
+        d[(int64_t)y * pitch + x] = s[i];
+    }
+}
+hipError_t launch_repack_frames(uint8_t *d_img, float *d_depth, int pitch, int64_t slot_elems, const uint8_t *s_img, const float *s_depth, int w, int h,
+                                int frames, hipStream_t st) {
+    const int n = w * h;
+    int blocks = (n + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (s_img) hipLaunchKernelGGL(k_repack_frames<uint8_t>, dim3(blocks, frames), dim3(256), 0, st, d_img, pitch, slot_elems, s_img, w, n);
+    if (s_depth) hipLaunchKernelGGL(k_repack_frames<float>, dim3(blocks, frames), dim3(256), 0, st, d_depth, pitch, slot_elems, s_depth, w, n);
+    return hipGetLastError();
+}
 hipError_t launch_repack(uint8_t *d_img, float *d_depth, int pitch, const uint8_t *s_img, const float *s_depth, int w, int h, hipStream_t st) {
     const int n = w * h;
     int blocks = (n + 255) / 256;

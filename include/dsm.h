@@ -251,7 +251,10 @@ int dsm_frame_upload_async(dsm_handle *h, int slot, const uint8_t *image, size_t
 /* n frames into slots slot0 .. slot0+n-1: frame i at image + i * img_frame_step / depth + i * depth_frame_step (bytes).
  * Frames laid out back to back exactly like the slots (row steps = the pitch, frame steps = pitch * height elements) go
  * up as ONE transfer per plane for all n -- a replay that keeps its frames in that layout pays two transfers per chunk
- * instead of two per frame. */
+ * instead of two per frame.  TIGHT rows (row steps = width elements, frames back to back) are taken too: one transfer per
+ * plane into a staging buffer of the handle (allocated at the first such call: that call waits for the upload stream) and
+ * a kernel that sets the rows to the slots' pitch -- 4.4 % fewer bytes over the link at 1226 pixels, yet measured SLOWER than
+ * the pitched layout (the kernel sits between two transfers of its stream); any other layout goes row by row. */
 int dsm_frames_upload_async(dsm_handle *h, int slot0, int n, const uint8_t *image, size_t img_step, size_t img_frame_step,
                             const float *depth, size_t depth_step, size_t depth_frame_step);
 int dsm_frame_uploads_wait(dsm_handle *h); /* blocks the host until this handle's asynchronous uploads have landed */

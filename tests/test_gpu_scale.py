@@ -236,8 +236,8 @@ def test_long_sequence_streamed_input(mods, seq_case):
     n, step, C = case["frames"], case["checkpoint_every"], 10
     period = scene.frames_per_period
 
-    def host_frames(ff):
-        pin = api.PinnedFrames(ff, period)  # the scene's period of frames in page-locked memory, slot pitch
+    def host_frames(ff, tight=False):
+        pin = api.PinnedFrames(ff, period, tight=tight)  # the scene's period of frames in page-locked memory: slot pitch, or tight rows
         for t in range(period):
             pin.set(t, frames[t][1], frames[t][2])
         return pin
@@ -265,10 +265,12 @@ def test_long_sequence_streamed_input(mods, seq_case):
     ff.close()
     pin.close()
 
-    # ---- eight handles in one batch, all streaming the same sequence from one page-locked copy
+    # ---- eight handles in one batch, all streaming the same sequence from one page-locked copy -- with TIGHT rows (width
+    # elements apart: no pad bytes over the link; the upload sets the rows to the slots' pitch on the device)
     B = 8
     handles = [api.FusionFunctions.from_camera(cam, frame_slots=2 * C, surfel_capacity=1 << 20, pipeline_depth=1) for _ in range(B)]
-    pin = host_frames(handles[0])
+    pin = host_frames(handles[0], tight=True)
+    assert pin.pitch == cam.width <= handles[0].frame_pitch()  # (640 pixels: tight IS the pitch)
     for h in handles:
         h.map_upload(np.zeros(0, api.SURFEL_DTYPE))
     batch = api.Batch(handles)
