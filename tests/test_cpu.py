@@ -362,6 +362,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert C.sizeof(api._Config) == 88  # 8 x 4 B + 4 doubles + 5 x 4 B, padded to 8
 
 
+def test_public_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: include/dsm.h, dsm_surfel_map.h and dsm_merge.h compile as C99 (no C++ in the signatures),
+    with warnings as errors, in a translation unit that calls across all three."""
+    src = tmp_path / "c_abi_check.c"
+    src.write_text('''#include "dsm.h"
+#include "dsm_surfel_map.h"
+#include "dsm_merge.h"
+int use(dsm_handle *h, const uint8_t *const *images, const size_t *is, const float *const *depths, const size_t *ds, uint8_t *di, float *dd) {
+    int32_t pitch = 0;
+    if (dsm_frame_pitch(h, &pitch)) return 1;
+    return dsm_host_pack_frames(1, 8, 8, images, is, depths, ds, di, (size_t)pitch, (size_t)pitch * 8, dd, (size_t)pitch * 4, (size_t)pitch * 32)
+         + dsm_merge_clouds_rccl(0, 1, 0, 0, 0, 0, 0, 0, 0);
+}
+''')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_host_pack_frames():
     """dsm_host_pack_frames (host code only: no GPU needed): the caller's frames -- contiguous and strided rows -- land in the
     slot layout row for row, pad bytes untouched; bad steps and null planes are refused before anything is copied."""
